@@ -1,0 +1,202 @@
+"""ctypes binding of the C-ABI library (include/semz_gpu.h).
+
+The library is the product: there is no Python or CPU decode path behind it.
+Importing this module without the built ``libsemz_gpu.so`` raises, and opening
+a context without a GPU raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsemz_gpu.so")
+
+
+class Unit(C.Structure):
+    _fields_ = [
+        ("in_off", C.c_uint64), ("in_limit", C.c_uint64),
+        ("out_off", C.c_uint64), ("out_cap", C.c_uint64),
+        ("kind", C.c_uint32), ("flags", C.c_uint32),
+        ("in_bit_off", C.c_uint32), ("param0", C.c_uint32),
+        ("param1", C.c_uint32), ("param2", C.c_uint32),
+        ("param3", C.c_uint32), ("reserved", C.c_uint32),
+        ("prefix_off", C.c_uint64), ("prefix_len", C.c_uint64),
+        ("size_in", C.c_uint64), ("size_out", C.c_uint64),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("detail", C.c_uint32),
+        ("in_end_bit", C.c_uint64), ("out_len", C.c_uint64),
+        ("check", C.c_uint8 * 32), ("check_len", C.c_uint32), ("aux", C.c_uint32),
+    ]
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("detail", C.c_uint32), ("total_out", C.c_uint64),
+        ("first_header", C.c_uint32 * 8), ("nmembers", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+# unit kinds / formats / flags (semz_gpu.h)
+UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2 = range(6)
+FMT_DEFLATE, FMT_ZLIB, FMT_GZIP, FMT_BZIP2, FMT_RAW_LZMA, FMT_LZMA, FMT_RAW_LZMA2, FMT_LZMA2, FMT_XZ = range(9)
+UF_HAVE_DICT_FN, UF_BCJ_X86, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE, UF_DELTA = 1, 2, 4, 8, 16
+
+_lib = None
+
+EXPORTS = [
+    "semz_open", "semz_close", "semz_last_error", "semz_strerror", "semz_decode_batch",
+    "semz_decode_batch_device", "semz_set_option", "semz_sync", "semz_stream",
+    "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
+    "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
+    "semz_split", "semz_free", "semz_decode_stream",
+]
+
+
+def load():
+    """Load libsemz_gpu.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    lib.semz_open.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.semz_close.argtypes = [vp]
+    lib.semz_close.restype = None
+    lib.semz_last_error.argtypes = [vp]
+    lib.semz_last_error.restype = C.c_char_p
+    lib.semz_strerror.argtypes = [C.c_int]
+    lib.semz_strerror.restype = C.c_char_p
+    lib.semz_decode_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(Unit), C.c_size_t,
+                                      vp, C.c_size_t, C.POINTER(Result)]
+    lib.semz_decode_batch_device.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp]
+    lib.semz_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    lib.semz_sync.argtypes = [vp]
+    lib.semz_stream.argtypes = [vp]
+    lib.semz_stream.restype = vp
+    lib.semz_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.semz_dev_free.argtypes = [vp, vp]
+    lib.semz_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.semz_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.semz_event_create.argtypes = [vp, C.POINTER(vp)]
+    lib.semz_event_record.argtypes = [vp, vp]
+    lib.semz_event_elapsed_ms.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
+    lib.semz_event_destroy.argtypes = [vp, vp]
+    lib.semz_split.argtypes = [C.c_int, C.c_char_p, C.c_size_t, u64p, u64p, C.c_size_t,
+                               C.POINTER(C.POINTER(Unit)), C.POINTER(C.c_size_t), C.POINTER(StreamInfo)]
+    lib.semz_free.argtypes = [vp]
+    lib.semz_free.restype = None
+    lib.semz_decode_stream.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
+                                       C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(Result),
+                                       C.POINTER(StreamInfo)]
+    _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    """API misuse or a HIP failure (not a data error)."""
+
+
+class Engine:
+    """One context on one GPU (semz_open / semz_close)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.semz_open(device, C.byref(h))
+        if rc != 0:
+            raise EngineError(f"semz_open(device={device}) failed with {rc}: no usable MI355X; "
+                              "this library has no CPU fallback")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.semz_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(f"rc={rc}: {self.lib.semz_last_error(self.h).decode()}")
+
+    def set_option(self, name, value):
+        self._chk(self.lib.semz_set_option(self.h, name.encode(), value))
+
+    def decode_batch(self, data, units, out_cap):
+        """Host-buffer batch decode. Returns (bytes-like output buffer, list of Result)."""
+        n = len(units)
+        uarr = (Unit * n)(*units)
+        res = (Result * n)()
+        out = C.create_string_buffer(max(out_cap, 1))
+        self._chk(self.lib.semz_decode_batch(self.h, bytes(data), len(data), uarr, n,
+                                             C.cast(out, C.c_void_p), out_cap, res))
+        return out, list(res)
+
+    # ---- device-resident API used by bench.py and the large-size tests ----
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.semz_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p
+
+    def dev_free(self, p):
+        self._chk(self.lib.semz_dev_free(self.h, p))
+
+    def upload(self, dptr, buf, nbytes=None, offset=0):
+        nbytes = len(buf) if nbytes is None else nbytes
+        src = (C.c_char * nbytes).from_buffer_copy(buf) if isinstance(buf, (bytes, bytearray, memoryview)) else buf
+        self._chk(self.lib.semz_dev_upload(self.h, C.c_void_p(dptr.value + offset), src, nbytes))
+
+    def download(self, dptr, nbytes, offset=0):
+        out = C.create_string_buffer(max(nbytes, 1))
+        self._chk(self.lib.semz_dev_download(self.h, out, C.c_void_p(dptr.value + offset), nbytes))
+        return out.raw[:nbytes]
+
+    def decode_batch_device(self, kind, d_in, in_len, d_units, nunits, d_out, out_cap, d_results):
+        self._chk(self.lib.semz_decode_batch_device(self.h, kind, d_in, in_len, d_units, nunits,
+                                                    d_out, out_cap, d_results))
+
+    def sync(self):
+        self._chk(self.lib.semz_sync(self.h))
+
+    def event(self):
+        e = C.c_void_p()
+        self._chk(self.lib.semz_event_create(self.h, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        self._chk(self.lib.semz_event_record(self.h, ev))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        self._chk(self.lib.semz_event_elapsed_ms(self.h, a, b, C.byref(ms)))
+        return ms.value
+
+    def decode_stream(self, fmt, data, all_members=True):
+        """decompress / decompress-all on the GPU. Returns (bytes, Result, StreamInfo)."""
+        out = C.c_void_p()
+        out_len = C.c_size_t()
+        res = Result()
+        info = StreamInfo()
+        self._chk(self.lib.semz_decode_stream(self.h, fmt, bytes(data), len(data), 1 if all_members else 0,
+                                              C.byref(out), C.byref(out_len), C.byref(res), C.byref(info)))
+        try:
+            payload = C.string_at(out, out_len.value) if out.value else b""
+        finally:
+            if out.value:
+                self.lib.semz_free(out)
+        return payload, res, info
+
+
+def strerror(status):
+    return load().semz_strerror(status).decode()

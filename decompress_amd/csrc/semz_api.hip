@@ -1,0 +1,236 @@
+// semz_api.hip -- the C ABI of include/semz_gpu.h: context, device memory
+// helpers, and the batched decode entry points that sequence the kernels.
+//
+// No CPU decode path exists in this library: every entry point that decodes
+// needs a HIP device and fails (negative return + semz_last_error) without one.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "semz_host.h"
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return semz_fail(ctx, -2, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return rc;
+}
+
+extern "C" int semz_open(int device, semz_ctx **out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -3;   // no GPU: nothing to fall back to
+    if (device < 0 || device >= ndev) return -1;
+    semz_ctx *c = new semz_ctx();
+    c->device = device;
+    c->inflate_group = 64;
+    if (const char *g = getenv("SEMZ_INFLATE_GROUP")) c->inflate_group = atoi(g);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -2; }
+    semz_check_tables *h = new semz_check_tables();
+    semz_build_check_tables(h);
+    hipError_t e = hipMalloc((void **)&c->d_tabs, sizeof(semz_check_tables));
+    if (e == hipSuccess) e = hipMemcpy(c->d_tabs, h, sizeof(semz_check_tables), hipMemcpyHostToDevice);
+    delete h;
+    if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return -2; }
+    *out = c;
+    return 0;
+}
+
+extern "C" void semz_close(semz_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &b : c->bufs) if (b.p) hipFree(b.p);
+    if (c->d_tabs) hipFree(c->d_tabs);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *semz_last_error(const semz_ctx *c) { return c ? c->err : "no context"; }
+
+extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
+{
+    if (!c || !name) return -1;
+    if (!strcmp(name, "inflate_group")) {
+        if (value != 16 && value != 32 && value != 64) return semz_fail(c, -1, "inflate_group must be 16, 32 or 64");
+        c->inflate_group = (int)value;
+        return 0;
+    }
+    return semz_fail(c, -1, "unknown option %s", name);
+}
+
+// grow-only device scratch owned by the context
+int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p)
+{
+    if ((size_t)slot >= c->bufs.size()) c->bufs.resize(slot + 1);
+    auto &b = c->bufs[slot];
+    if (b.cap < bytes) {
+        hipSetDevice(c->device);
+        if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        size_t cap = bytes + bytes / 4 + 256;
+        HIPCHK(c, hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *p = b.p;
+    return 0;
+}
+
+extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *d_in, size_t in_len,
+                                        const semz_unit *d_units, size_t nunits, void *d_out,
+                                        size_t out_cap, semz_result *d_results)
+{
+    if (!c) return -1;
+    if (nunits == 0) return 0;
+    if (!d_in || !d_units || !d_out || !d_results) return semz_fail(c, -1, "null device pointer");
+    if (nunits > 0xFFFFFFF0u) return semz_fail(c, -1, "too many units");
+    (void)in_len; (void)out_cap;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *tails = nullptr;
+    int rc = semz_scratch(c, SEMZ_SLOT_TAILS, nunits * sizeof(semz_tail), &tails);
+    if (rc) return rc;
+    switch (kind) {
+    case SEMZ_UNIT_DEFLATE:
+    case SEMZ_UNIT_ZLIB:
+    case SEMZ_UNIT_GZIP:
+        semz_launch_inflate(c->inflate_group, (const uint8_t *)d_in, d_units, (uint32_t)nunits, (uint8_t *)d_out,
+                            d_results, (semz_tail *)tails, c->stream);
+        semz_launch_checksum((const uint8_t *)d_out, d_units, (uint32_t)nunits, d_results, (const semz_tail *)tails,
+                             c->d_tabs, (1u << SEMZ_TK_CRC32) | (1u << SEMZ_TK_ADLER32), c->stream);
+        break;
+    case SEMZ_UNIT_BZIP2_BLOCK:
+        rc = semz_run_bzip2(c, (const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,
+                            d_results, (semz_tail *)tails);
+        if (rc) return rc;
+        break;
+    case SEMZ_UNIT_XZ_BLOCK:
+    case SEMZ_UNIT_LZMA2:
+        rc = semz_run_lzma2(c, (const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,
+                            d_results, (semz_tail *)tails);
+        if (rc) return rc;
+        break;
+    default:
+        return semz_fail(c, -1, "unknown unit kind %u", kind);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" int semz_sync(semz_ctx *c)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" void *semz_stream(semz_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" int semz_decode_batch(semz_ctx *c, const uint8_t *in, size_t in_len, const semz_unit *units,
+                                 size_t nunits, uint8_t *out, size_t out_cap, semz_result *results)
+{
+    if (!c) return -1;
+    if (nunits == 0) return 0;
+    if (!in || !units || !results || (!out && out_cap)) return semz_fail(c, -1, "null pointer");
+    // host-side validation of every span the kernels will touch
+    uint64_t out_hi = 0;
+    uint32_t fam = units[0].kind <= SEMZ_UNIT_GZIP ? 0 : units[0].kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : 2;
+    for (size_t i = 0; i < nunits; i++) {
+        const semz_unit &u = units[i];
+        uint32_t f = u.kind <= SEMZ_UNIT_GZIP ? 0 : u.kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : 2;
+        if (u.kind > SEMZ_UNIT_LZMA2 || f != fam) return semz_fail(c, -1, "unit %zu: mixed or unknown kind", i);
+        if (u.in_off > u.in_limit || u.in_limit > in_len) return semz_fail(c, -1, "unit %zu: input span out of range", i);
+        if (u.out_off > out_cap || u.out_cap > out_cap - u.out_off) return semz_fail(c, -1, "unit %zu: output span out of range", i);
+        if (u.prefix_len && (u.prefix_off > in_len || u.prefix_len > in_len - u.prefix_off))
+            return semz_fail(c, -1, "unit %zu: prefix span out of range", i);
+        if (u.in_bit_off > 7) return semz_fail(c, -1, "unit %zu: bit offset", i);
+        if (u.out_off + u.out_cap > out_hi) out_hi = u.out_off + u.out_cap;
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    void *d_in, *d_units, *d_out, *d_res;
+    int rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_IN, in_len + 16, &d_in))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_UNITS, nunits * sizeof(semz_unit), &d_units))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_OUT, out_hi + 16, &d_out))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_RES, nunits * sizeof(semz_result), &d_res))) return rc;
+    HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_units, units, nunits * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_res, 0xFF, nunits * sizeof(semz_result), c->stream));
+    rc = semz_decode_batch_device(c, units[0].kind, d_in, in_len, (const semz_unit *)d_units, nunits, d_out, out_hi,
+                                  (semz_result *)d_res);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(results, d_res, nunits * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));
+    if (out_hi) HIPCHK(c, hipMemcpyAsync(out, d_out, out_hi, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int semz_dev_alloc(semz_ctx *c, size_t bytes, void **p)
+{
+    if (!c || !p) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMalloc(p, bytes ? bytes : 1));
+    return 0;
+}
+extern "C" int semz_dev_free(semz_ctx *c, void *p)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipFree(p));
+    return 0;
+}
+extern "C" int semz_dev_upload(semz_ctx *c, void *d, const void *s, size_t n)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int semz_dev_download(semz_ctx *c, void *d, const void *s, size_t n)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" int semz_event_create(semz_ctx *c, void **ev)
+{
+    if (!c || !ev) return -1;
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreate(&e));
+    *ev = (void *)e;
+    return 0;
+}
+extern "C" int semz_event_record(semz_ctx *c, void *ev)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipEventRecord((hipEvent_t)ev, c->stream));
+    return 0;
+}
+extern "C" int semz_event_elapsed_ms(semz_ctx *c, void *a, void *b, float *ms)
+{
+    if (!c || !ms) return -1;
+    HIPCHK(c, hipEventSynchronize((hipEvent_t)b));
+    HIPCHK(c, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return 0;
+}
+extern "C" int semz_event_destroy(semz_ctx *c, void *ev)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipEventDestroy((hipEvent_t)ev));
+    return 0;
+}
+extern "C" void semz_free(void *p) { free(p); }

@@ -1,0 +1,86 @@
+// semz_device.h -- device-side helpers shared by the gfx950 kernels.
+//
+// Execution model used by every decode kernel in this library: one workgroup
+// = one 64-lane wavefront; a wavefront is split into 64/G "groups" of G
+// consecutive lanes and each group owns one unit.  Lane 0 of a group (the
+// "leader") runs the bit-serial entropy decode; all G lanes run the
+// data-parallel parts (table construction, match copies, ring flushes).
+// Because a workgroup is a single wave, LDS hand-offs between lanes need no
+// s_barrier: LDS operations of one wave execute in program order, and
+// lds_sync() only stops the compiler from moving LDS accesses across it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/semz_gpu.h"
+
+#define SEMZ_WAVE 64
+
+// What the decode kernels leave for the checksum/verify kernels.
+struct semz_tail {
+    uint32_t want[8];     // expected check value (little-endian words) read from the trailer
+    uint32_t have_check;  // 1 = the check field was present (0 = input ended first -> EOF)
+    uint32_t have_isize;  // gzip: ISIZE field present
+    uint32_t want_isize;
+    uint32_t check_kind;  // SEMZ_TK_*
+    uint64_t trailer_end_bit; // in_end_bit if every trailer field was present
+    uint64_t pad;
+};
+enum { SEMZ_TK_NONE = 0, SEMZ_TK_CRC32 = 1, SEMZ_TK_ADLER32 = 2, SEMZ_TK_BZCRC = 3,
+       SEMZ_TK_CRC64 = 4, SEMZ_TK_SHA256 = 5 };
+
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int G> struct Group {
+    static_assert(G == 64 || G == 32 || G == 16 || G == 8 || G == 4, "group size");
+    __device__ __forceinline__ static int lane() { return threadIdx.x & 63; }
+    __device__ __forceinline__ static int gl() { return lane() & (G - 1); }
+    __device__ __forceinline__ static int base() { return lane() & ~(G - 1); }
+    // value held by the group's leader
+    template <typename T> __device__ __forceinline__ static T bcast(T v)
+    {
+        if constexpr (sizeof(T) == 8) {
+            uint32_t lo = (uint32_t)(uint64_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+            lo = bcast(lo);
+            hi = bcast(hi);
+            return (T)(((uint64_t)hi << 32) | lo);
+        } else if constexpr (G == 64) {
+            return (T)__builtin_amdgcn_readfirstlane((int)v);
+        } else {
+            return (T)__shfl((int)v, base(), 64);
+        }
+    }
+    __device__ __forceinline__ static uint64_t ballot(bool p)
+    {
+        uint64_t m = __ballot(p);
+        if constexpr (G == 64) return m;
+        else return (m >> base()) & ((1ull << G) - 1);
+    }
+};
+
+// unaligned little-endian loads from global memory
+__device__ __forceinline__ uint64_t ld_u64(const uint8_t *p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+// bytes [pos, pos+8) of a buffer that ends at `limit`; bytes beyond read as zero
+__device__ __forceinline__ uint64_t ld_u64_clamped(const uint8_t *base, uint64_t pos, uint64_t limit)
+{
+    if (pos + 8 <= limit) return ld_u64(base + pos);
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++)
+        if (pos + i < limit) v |= (uint64_t)base[pos + i] << (8 * i);
+    return v;
+}

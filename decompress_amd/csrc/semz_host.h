@@ -1,0 +1,48 @@
+// semz_host.h -- host-side internals of the library (context, kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "semz_device.h"
+
+struct semz_check_tables {
+    uint32_t crc32[4][256];     // reflected 0xEDB88320, slice-by-4
+    uint32_t bzcrc[4][256];     // MSB-first 0x04C11DB7, slice-by-4
+    uint64_t crc64[4][256];     // reflected 0xC96C5795D7870F42, slice-by-4
+    uint32_t x2n32[32];         // x^(2^k) mod P, reflected CRC-32 representation
+    uint32_t x2nbz[32];         // same, MSB-first representation
+    uint64_t x2n64[64];         // same, reflected CRC-64
+};
+
+struct semz_devbuf { void *p = nullptr; size_t cap = 0; };
+
+struct semz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    semz_check_tables *d_tabs = nullptr;
+    int inflate_group = 64;
+    std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
+    char err[512] = {0};
+};
+
+enum {
+    SEMZ_SLOT_TAILS = 0, SEMZ_SLOT_IN, SEMZ_SLOT_UNITS, SEMZ_SLOT_OUT, SEMZ_SLOT_RES,
+    SEMZ_SLOT_BZ_META, SEMZ_SLOT_BZ_DATA, SEMZ_SLOT_BZ_TT, SEMZ_SLOT_BZ_AUX,
+    SEMZ_SLOT_LZ_META, SEMZ_SLOT_STREAM_A, SEMZ_SLOT_STREAM_B, SEMZ_SLOT_STREAM_C,
+    SEMZ_SLOT_COUNT
+};
+
+int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...);
+int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p);
+
+extern "C" {
+void semz_build_check_tables(semz_check_tables *t);
+void semz_launch_inflate(int group, const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
+                         uint8_t *d_out, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
+void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32_t nunits,
+                          semz_result *d_results, const semz_tail *d_tails,
+                          const semz_check_tables *d_tabs, uint32_t kind_mask, hipStream_t stream);
+}
+int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);
+int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);

@@ -1,0 +1,193 @@
+/*
+ * semz_gpu.h -- C ABI of the MI355X batched decode engine for se-mz/decompress.
+ *
+ * The reference is pure Common Lisp with no FFI (README.org:28); its "plugin
+ * API" for a format is three generic functions (common.lisp:262-289):
+ *
+ *   byte-source->decompression-state (format byte-source &key)  -> state, header
+ *   next-decompressed-chunk (state)                             -> chunk start end finalp
+ *   make-reset-state (old-state)                                -> new-state | nil
+ *
+ * and all decode time is spent inside next-decompressed-chunk methods
+ * (SURVEY.md section 3a).  This library replaces "one next-decompressed-chunk loop
+ * per unit, serially" by "one device call for a batch of independent units".
+ * The entry points below are what a CFFI binding in the Lisp host would bind
+ * (INTEGRATION.md shows the stub); plain pointers and sizes only.
+ *
+ * A "unit" is one independently decodable piece:
+ *   a gzip member      (gzip.lisp:31-115; independence: gzip.lisp:89-93)
+ *   a zlib member      (zlib.lisp:21-78)
+ *   a raw deflate member (deflate.lisp:365-433)
+ *   a bzip2 block      (bzip2.lisp:351-395, 456-526)
+ *   an xz block        (xz.lisp:260-457, lzma2.lisp:77-204)
+ *   a raw LZMA2 stream (lzma2.lisp:206-218)
+ *
+ * Status codes: semz_status.h (one per `die` site on the path).
+ * Return values of the functions: 0 on success, negative on API misuse or a
+ * HIP failure (semz_last_error() has the text).  Data errors never make a call
+ * fail: they are reported per unit in semz_result.status.
+ */
+#ifndef SEMZ_GPU_H
+#define SEMZ_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "semz_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* format keywords of the reference (example.lisp:77-78) */
+enum {
+    SEMZ_FMT_DEFLATE = 0, SEMZ_FMT_ZLIB = 1, SEMZ_FMT_GZIP = 2, SEMZ_FMT_BZIP2 = 3,
+    SEMZ_FMT_RAW_LZMA = 4, SEMZ_FMT_LZMA = 5, SEMZ_FMT_RAW_LZMA2 = 6, SEMZ_FMT_LZMA2 = 7,
+    SEMZ_FMT_XZ = 8
+};
+
+/* unit kinds */
+enum {
+    SEMZ_UNIT_DEFLATE = 0,     /* raw deflate member starting at in_off */
+    SEMZ_UNIT_ZLIB = 1,        /* zlib member: 2(+4) byte header, deflate, Adler-32 BE */
+    SEMZ_UNIT_GZIP = 2,        /* gzip member: header, deflate, CRC-32 + ISIZE */
+    SEMZ_UNIT_BZIP2_BLOCK = 3, /* block whose 48-bit magic starts at (in_off, in_bit_off) */
+    SEMZ_UNIT_XZ_BLOCK = 4,    /* LZMA2 payload of an xz block (+ filters, + check) */
+    SEMZ_UNIT_LZMA2 = 5        /* raw LZMA2 chunk sequence */
+};
+
+/* semz_unit.flags */
+enum {
+    SEMZ_UF_HAVE_DICT_FN = 1u << 0,  /* zlib: caller has a dictionary function (zlib.lisp:43-44) */
+    SEMZ_UF_BCJ_X86 = 1u << 1,       /* xz: x86 BCJ filter precedes LZMA2 (xz.lisp:323-344) */
+    SEMZ_UF_HAVE_IN_SIZE = 1u << 2,  /* xz: block header declares a compressed size */
+    SEMZ_UF_HAVE_OUT_SIZE = 1u << 3, /* xz: block header declares an uncompressed size */
+    SEMZ_UF_DELTA = 1u << 4          /* xz: delta filter precedes LZMA2 (param3 = distance) */
+};
+
+/* xz check types (xz.lisp:12-31) */
+enum { SEMZ_CHECK_NONE = 0, SEMZ_CHECK_CRC32 = 1, SEMZ_CHECK_CRC64 = 4, SEMZ_CHECK_SHA256 = 10 };
+
+typedef struct semz_unit {
+    uint64_t in_off;      /* byte offset of the unit inside `in` */
+    uint64_t in_limit;    /* one past the last byte this unit may read: reads beyond are
+                             `eof` (io.lisp:93-104).  In all-members mode this is the end of
+                             the input, because the reference's bit readers may look ahead
+                             into the next member (interface.lisp:81-84). */
+    uint64_t out_off;     /* byte offset of the unit's output inside `out` */
+    uint64_t out_cap;     /* bytes available at out_off; exceeding it is SEMZ_E_OUT_CAP */
+    uint32_t kind;        /* SEMZ_UNIT_* */
+    uint32_t flags;       /* SEMZ_UF_* */
+    uint32_t in_bit_off;  /* bzip2: bit offset 0..7 (MSB-first) of the magic inside byte in_off */
+    uint32_t param0;      /* deflate: window size (0 = 32768); bzip2: level 1..9; lzma2/xz: dictionary size */
+    uint32_t param1;      /* xz: check type */
+    uint32_t param2;      /* xz: BCJ start offset (xz.lisp:326-331) */
+    uint32_t param3;      /* xz: delta distance 1..256 */
+    uint32_t reserved;
+    uint64_t prefix_off;  /* deflate/zlib preset history: span inside `in` (deflate.lisp:419-425) */
+    uint64_t prefix_len;
+    uint64_t size_in;     /* xz: declared compressed size (SEMZ_UF_HAVE_IN_SIZE) */
+    uint64_t size_out;    /* xz: declared uncompressed size (SEMZ_UF_HAVE_OUT_SIZE) */
+} semz_unit;
+
+typedef struct semz_result {
+    int32_t  status;      /* semz_status */
+    uint32_t detail;      /* first argument of the reference's message (bad code, ...) */
+    uint64_t in_end_bit;  /* bit offset inside `in` one past the last bit the unit consumed,
+                             trailer included: unit k+1 starts at ceil(in_end_bit / 8) */
+    uint64_t out_len;     /* bytes written at out_off */
+    uint8_t  check[32];   /* computed checksum as the little-endian byte string the reference
+                             compares (crc32/adler32/bzip2 crc: 4, crc64: 8, sha256: 32) */
+    uint32_t check_len;
+    uint32_t aux;         /* zlib: dictionary id when FDICT; gzip: header length */
+} semz_result;
+
+typedef struct semz_ctx semz_ctx;
+
+/* Opens the engine on one GPU (one context per process per GPU; calls on one
+ * context must not overlap).  device = HIP device ordinal. */
+int semz_open(int device, semz_ctx **ctx);
+void semz_close(semz_ctx *ctx);
+const char *semz_last_error(const semz_ctx *ctx);
+
+/* Reference message text for a status (common.lisp:53-57 and the `die` sites). */
+const char *semz_strerror(int status);
+
+/* Batched decode, host buffers: uploads in[0..in_len) and the unit table,
+ * runs the kernels, downloads out[0..out_cap) spans of the units and results.
+ * Replaces the per-unit next-decompressed-chunk loops (deflate.lisp:365-410,
+ * gzip.lisp:95-115, zlib.lisp:59-78, bzip2.lisp:456-526, xz.lisp:381-457). */
+int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
+                      const semz_unit *units, size_t nunits,
+                      uint8_t *out, size_t out_cap, semz_result *results);
+/* All units of one call belong to one family: SEMZ_UNIT_DEFLATE/ZLIB/GZIP may
+ * be mixed; SEMZ_UNIT_BZIP2_BLOCK alone; SEMZ_UNIT_XZ_BLOCK/LZMA2 may be mixed. */
+
+/* Same, everything device-resident (d_* are device pointers of this ctx's GPU);
+ * asynchronous on the context's stream until semz_sync().  `kind` names the
+ * family of the batch (any SEMZ_UNIT_* value of that family).  This is the
+ * call the benchmark times. */
+int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
+                             const semz_unit *d_units, size_t nunits,
+                             void *d_out, size_t out_cap, semz_result *d_results);
+/* Tunables: "inflate_group" = lanes per deflate unit (16, 32 or 64). */
+int semz_set_option(semz_ctx *ctx, const char *name, long value);
+int semz_sync(semz_ctx *ctx);
+/* The HIP stream the kernels run on (hipStream_t), for event timing. */
+void *semz_stream(semz_ctx *ctx);
+
+/* Device memory helpers so that hosts without a HIP binding (ctypes, CFFI) can
+ * stage buffers. */
+int semz_dev_alloc(semz_ctx *ctx, size_t bytes, void **dptr);
+int semz_dev_free(semz_ctx *ctx, void *dptr);
+int semz_dev_upload(semz_ctx *ctx, void *dptr, const void *src, size_t bytes);
+int semz_dev_download(semz_ctx *ctx, void *dst, const void *dptr, size_t bytes);
+/* HIP events on the context's stream: record two, read the elapsed ms. */
+int semz_event_create(semz_ctx *ctx, void **ev);
+int semz_event_record(semz_ctx *ctx, void *ev);
+int semz_event_elapsed_ms(semz_ctx *ctx, void *ev_start, void *ev_stop, float *ms);
+int semz_event_destroy(semz_ctx *ctx, void *ev);
+
+/* ---- host splitter ----
+ * Finds the independent units of a multi-unit input without decoding it.
+ *   gzip/zlib/deflate: caller-supplied member offsets (offsets[noffsets], ascending,
+ *     offsets[0] == 0), e.g. a BGZF index or a record table; with noffsets == 0 a
+ *     gzip input is walked through its BGZF "BC" extra subfields (gzip.lisp:10-29);
+ *     if it has none the whole input is one unit chain (see semz_decode_stream).
+ *   bzip2: stream header (bzip2.lisp:425-449) + bit-granular scan for the 48-bit
+ *     block / footer magics (bzip2.lisp:460-503); candidates are validated after
+ *     decoding by chaining in_end_bit (semz_decode_stream does this).
+ *   xz: stream header (xz.lisp:78-112), then footer -> index -> block offsets
+ *     (xz.lisp:166-233), block headers parsed on the host (xz.lisp:260-379).
+ * out_sizes (optional, noffsets entries) gives each member's output size when
+ * the caller knows it (zlib/deflate records); gzip members take ISIZE.
+ * The returned table is malloc'ed; release it with semz_free(). */
+typedef struct semz_stream_info {
+    int32_t  status;        /* container-level parse status (semz_status) */
+    uint32_t detail;
+    uint64_t total_out;     /* sum of out_cap over units when known, else 0 */
+    uint32_t first_header[8];/* format-specific first-member header words, see INTEGRATION.md */
+    uint32_t nmembers;      /* streams/members seen (bzip2, xz) */
+    uint32_t reserved;
+} semz_stream_info;
+
+int semz_split(int fmt, const uint8_t *in, size_t in_len,
+               const uint64_t *offsets, const uint64_t *out_sizes, size_t noffsets,
+               semz_unit **units, size_t *nunits, semz_stream_info *info);
+void semz_free(void *p);
+
+/* decompress-all for a fully buffered input (interface.lisp:188-208): split,
+ * decode every unit on the GPU, verify the cross-unit invariants on the host
+ * in unit order (bzip2 stream CRC fold bzip2.lisp:42-49,489-494; xz index and
+ * footer xz.lisp:166-233; "unit k ends where unit k+1 starts"; trailing data
+ * interface.lisp:125-130), first error wins.  *out is malloc'ed (semz_free).
+ * res->status is the stream's status; res->out_len the total output;
+ * res->in_end_bit/8 the bytes consumed.  all_members == 0 decodes the first
+ * member only (interface.lisp:149-186). */
+int semz_decode_stream(semz_ctx *ctx, int fmt, const uint8_t *in, size_t in_len,
+                       int all_members, uint8_t **out, size_t *out_len,
+                       semz_result *res, semz_stream_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEMZ_GPU_H */
