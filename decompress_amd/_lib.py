@@ -52,6 +52,7 @@ EXPORTS = [
     "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
     "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
     "semz_split", "semz_free", "semz_decode_stream",
+    "semz_profile_count", "semz_profile_get", "semz_profile_reset",
 ]
 
 
@@ -95,6 +96,10 @@ def load():
     lib.semz_decode_stream.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
                                        C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(Result),
                                        C.POINTER(StreamInfo)]
+    lib.semz_profile_count.argtypes = [vp]
+    lib.semz_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
+    lib.semz_profile_reset.argtypes = [vp]
+    lib.semz_profile_reset.restype = None
     _lib = lib
     return lib
 
@@ -181,6 +186,17 @@ class Engine:
         ms = C.c_float()
         self._chk(self.lib.semz_event_elapsed_ms(self.h, a, b, C.byref(ms)))
         return ms.value
+
+    def profile(self, reset=True):
+        """[(kernel name, ms)] for the calls since the last reset ("profile" option on)."""
+        out = []
+        for i in range(self.lib.semz_profile_count(self.h)):
+            name, ms = C.c_char_p(), C.c_float()
+            self._chk(self.lib.semz_profile_get(self.h, i, C.byref(name), C.byref(ms)))
+            out.append((name.value.decode(), ms.value))
+        if reset:
+            self.lib.semz_profile_reset(self.h)
+        return out
 
     def decode_stream(self, fmt, data, all_members=True):
         """decompress / decompress-all on the GPU. Returns (bytes, Result, StreamInfo)."""

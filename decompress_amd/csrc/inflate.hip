@@ -28,6 +28,7 @@ constexpr int DIST_ROOT_BITS = 8;
 constexpr int CLEN_ROOT_BITS = 7;
 constexpr int RING = 4096;               // output staging ring per unit (bytes)
 constexpr int RING_MASK = RING - 1;
+constexpr int IN_RING = 2048;            // compressed-input staging ring per unit (bytes)
 constexpr int ROUND_BYTES = 2048;        // a round stops once it has produced this many bytes
 constexpr int MIN_BLOCK_BITS = 10;       // +min-deflate-block-bitsize+, deflate.lisp:4-12
 
@@ -58,6 +59,7 @@ template <int G> struct __align__(16) UnitLds {
     uint32_t dist_root[1 << DIST_ROOT_BITS];
     uint32_t queue[2 * G];
     uint8_t ring[RING];
+    uint8_t inring[IN_RING];
     uint16_t lit_sorted[288];
     uint8_t dist_sorted[32];
     uint8_t clen_sorted[32];
@@ -158,40 +160,86 @@ __device__ void build_tree(const uint8_t *lens, int n, TreeMeta &m, SortT *sorte
     lds_sync();
 }
 
+// LSB-first bit reader (lsb-bit-reader, bits.lisp:118) over the unit's LDS
+// input ring.  Positions are "v-offsets": byte offset inside `in` plus the
+// 16-byte misalignment of the `in` pointer, so that v % 16 == address % 16 and
+// the ring can be filled with aligned 16-byte loads (stage_input).  The ring
+// holds zero bytes past the end of the unit's input; near_end turns on the
+// exact end-of-input accounting that decides `eof` (bits.lisp:35-45).
 struct BitReader {
-    const uint8_t *base;
-    uint64_t pos;     // next byte to load (may run past limit virtually)
-    uint64_t limit;   // first byte that must not be read
+    const uint8_t *ring;
+    uint64_t wpos;    // v-offset of the next dword to take from the ring (multiple of 4)
+    uint64_t limit;   // v-offset of the first byte that does not exist
     uint64_t buf;
-    int cnt;          // bits in buf (including virtual zero bits past the limit)
-    bool near_end;    // a refill touched the limit: exact end-of-input checks are on
+    int cnt;          // bits in buf
+    int skip;         // bits to discard from the first dword (unaligned start)
+    bool near_end;
 
-    __device__ __forceinline__ void init(const uint8_t *b, uint64_t p, uint64_t lim)
+    __device__ __forceinline__ void init(const uint8_t *r, uint64_t v, uint64_t lim)
     {
-        base = b; pos = p; limit = lim; buf = 0; cnt = 0; near_end = false;
+        ring = r; wpos = v & ~3ull; limit = lim; buf = 0; cnt = 0; skip = (int)(v & 3) * 8; near_end = false;
     }
+    __device__ __forceinline__ uint32_t next_dword()
+    {
+        uint32_t w = *reinterpret_cast<const uint32_t *>(ring + (wpos & (IN_RING - 1)));
+        if (wpos + 4 > limit) near_end = true;
+        wpos += 4;
+        return w;
+    }
+    // after refill(): cnt >= 33
     __device__ __forceinline__ void refill()
     {
-        if (cnt > 55) return;
-        uint64_t w;
-        if (pos + 8 <= limit) w = ld_u64(base + pos);
-        else { w = ld_u64_clamped(base, pos, limit); near_end = true; }
-        buf |= w << cnt;
-        int nb = (63 - cnt) >> 3;
-        pos += nb;
-        cnt += nb * 8;
+        if (skip) {
+            buf = (uint64_t)next_dword() >> skip;
+            cnt = 32 - skip;
+            skip = 0;
+        }
+        if (cnt <= 32) {
+            buf |= (uint64_t)next_dword() << cnt;
+            cnt += 32;
+        }
     }
-    // bits left between the read position and the end of the input (bits.lisp:35-45)
+    // bits left between the read position and the end of the input
     __device__ __forceinline__ int64_t remaining() const
     {
-        return (int64_t)(8 * limit) + cnt - (int64_t)(8 * pos);
+        return (int64_t)(8 * limit) - (int64_t)(8 * wpos) + cnt - skip;
     }
     __device__ __forceinline__ bool short_of(int n) const { return near_end && remaining() < n; }
-    __device__ __forceinline__ uint64_t bitpos() const { return 8 * pos - (uint64_t)cnt; }
+    // bit position as a v-offset in bits
+    __device__ __forceinline__ uint64_t bitpos() const { return 8 * wpos - (uint64_t)cnt + (uint64_t)skip; }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)buf & ((1u << n) - 1); }
     __device__ __forceinline__ void drop(int n) { buf >>= n; cnt -= n; }
     __device__ __forceinline__ void align_byte() { int d = cnt & 7; buf >>= d; cnt -= d; }
 };
+
+// Group-cooperative top-up of the input ring with aligned 16-byte loads:
+// after the call at least IN_RING - 16*G staged bytes lie ahead of wpos.
+// Bytes outside [in_lo, limit) (v-offsets) are staged as zero.
+template <int G>
+__device__ __forceinline__ void stage_input(uint8_t *ring, const uint8_t *in_v0, uint64_t in_lo, uint64_t limit,
+                                            uint64_t wpos, uint64_t &s_hi)
+{
+    const int gl = Group<G>::gl();
+    const uint64_t wfloor = wpos & ~15ull;
+    if (s_hi < wfloor || s_hi > wfloor + IN_RING) s_hi = wfloor;      // first call, or the reader jumped ahead
+    while (s_hi + 16u * G <= wfloor + IN_RING) {
+        const uint64_t v = s_hi + 16u * gl;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (v >= in_lo && v + 16 <= limit) {
+            x = *reinterpret_cast<const uint4 *>(in_v0 + v);
+        } else if (v < limit && v + 16 > in_lo) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 16; b++) {
+                uint64_t vv = v + b;
+                if (vv >= in_lo && vv < limit) w[b >> 2] |= (uint32_t)in_v0[vv] << (8 * (b & 3));
+            }
+            x = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4 *>(ring + (v & (IN_RING - 1))) = x;
+        s_hi += 16u * G;
+    }
+    lds_sync();
+}
 
 struct Status {
     int32_t code;
@@ -274,9 +322,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
     const uint64_t out_cap = un.out_cap;
 
     // ---- leader-only state ----
+    // v-offsets (see BitReader): offset inside `in` + misalignment of the `in` pointer
+    const uint64_t amis = (uint64_t)((uintptr_t)in & 15);
+    const uint8_t *in_v0 = in - amis;                // in_v0 + v is the address of v-offset v
+    const uint64_t limit_v = un.in_limit + amis;
+    uint64_t s_hi = 0;                               // input staged up to this v-offset (group-uniform)
     BitReader br;
     Status st{SEMZ_OK, 0};
-    br.init(in, un.in_off, un.in_limit);
+    br.init(L.inring, un.in_off + amis, limit_v);
     uint32_t wsize = un.param0 ? un.param0 : 32768u;
     uint64_t prefix_amount = 0;
     const uint8_t *prefix_end = in;      // one past the last history byte
@@ -300,7 +353,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
         if (un.kind == SEMZ_UNIT_GZIP) {
             uint64_t p = parse_gzip_header(in, un.in_off, un.in_limit, st);
             aux = (uint32_t)(p - un.in_off);
-            br.init(in, p, un.in_limit);
+            br.init(L.inring, p + amis, limit_v);
             wsize = 32768u;
         } else if (un.kind == SEMZ_UNIT_ZLIB) {          // zlib.lisp:21-57
             uint64_t p = un.in_off;
@@ -324,7 +377,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                         }
                     }
                 }
-                br.init(in, p, un.in_limit);
+                br.init(L.inring, p + amis, limit_v);
             }
         }
         if (un.prefix_len) {                              // deflate.lisp:419-425
@@ -342,10 +395,17 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
     while (__any(alive)) {
         int ev = EV_DONE;
         uint32_t ntok = 0, rbytes = 0;
+        // top up the input ring ahead of the reader (all lanes)
+        {
+            uint64_t wp = Gr::bcast(br.wpos);
+            if (alive) stage_input<G>(L.inring, in_v0, amis, limit_v, wp, s_hi);
+        }
         if (leader && alive) {
             ev = EV_ROUND;
             if (st.code != SEMZ_OK) ev = EV_DONE;
-            while (ev == EV_ROUND && ntok < (uint32_t)G && rbytes < (uint32_t)ROUND_BYTES) {
+            // every iteration takes at most five dwords from the ring
+            while (ev == EV_ROUND && ntok < (uint32_t)G && rbytes < (uint32_t)ROUND_BYTES &&
+                   br.wpos + 32 <= s_hi) {
                 br.refill();
                 if (state == ST_HDR) {
                     if (final_block) { finished = true; ev = EV_DONE; break; }
@@ -397,15 +457,15 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                     // raw bytes: the bit buffer is byte aligned; hand the span to the group
                     uint32_t room = ROUND_BYTES - rbytes;
                     uint32_t n = stored_left < room ? stored_left : room;
-                    uint64_t src = br.bitpos() >> 3;
+                    uint64_t src = br.bitpos() >> 3;              // v-offset of the span
                     L.queue[2 * ntok] = T_RAW | (n << 2) | (rbytes << 16);
-                    L.queue[2 * ntok + 1] = (uint32_t)(src - un.in_off);
+                    L.queue[2 * ntok + 1] = (uint32_t)(src - amis - un.in_off);
                     ntok++;
                     rbytes += n;
                     stored_left -= n;
-                    br.init(in, src + n, un.in_limit);   // restart the bit buffer after the span
+                    br.init(L.inring, src + n, limit_v);          // restart the bit buffer after the span
                     if (stored_left == 0) state = ST_HDR;
-                    continue;
+                    break;                                        // the ring must be restaged at the new position
                 }
                 // ---- ST_HUFF: one literal/length symbol, decode-huffman-data deflate.lisp:313-338 ----
                 uint32_t e = L.lit_root[br.peek(LIT_ROOT_BITS)];
@@ -434,6 +494,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                 if (br.short_of(lx)) { st.set(SEMZ_EOF, 0); ev = EV_DONE; break; }
                 uint32_t length = ((e >> 11) & 0x1FF) + br.peek(lx);
                 br.drop(lx);
+                br.refill();
                 uint32_t d = L.dist_root[br.peek(DIST_ROOT_BITS)];
                 uint32_t dl = d & 15;
                 if (dl == 0) {
@@ -556,6 +617,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                 // code-length tree, then the code lengths themselves (deflate.lisp:176-197)
                 build_tree<G, CLEN_ROOT_BITS>(L.clens, 19, L.clen, L.clen_sorted, L.clen_root, clen_entry);
                 tstatus = L.clen.status;
+                {   // the code lengths take at most 320 * 14 bits: make sure they are staged
+                    uint64_t wp = Gr::bcast(br.wpos);
+                    stage_input<G>(L.inring, in_v0, amis, limit_v, wp, s_hi);
+                }
                 if (leader) {
                     overread = (final_block ? 0 : MIN_BLOCK_BITS) + trailing_bits;    // deflate.lisp:392-396
                     if (tstatus == SEMZ_OK) {
@@ -646,7 +711,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                 semz_result r{};
                 if (st.code == SEMZ_OK && finished) {
                     // the trailer is byte aligned: read it straight from memory
-                    uint64_t bp = (br.bitpos() + 7) >> 3, endb = bp;
+                    uint64_t bp = ((br.bitpos() + 7) >> 3) - amis, endb = bp;    // offset inside `in`
                     if (un.kind == SEMZ_UNIT_GZIP) {            // gzip.lisp:102-113
                         t.check_kind = SEMZ_TK_CRC32;
                         if (un.in_limit >= bp + 4) {
@@ -660,12 +725,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                         }
                         t.have_isize = 1; t.want_isize = (uint32_t)pos;
                     }
-                    if (un.kind != SEMZ_UNIT_DEFLATE) br.init(in, endb, un.in_limit);
+                    if (un.kind != SEMZ_UNIT_DEFLATE) br.init(L.inring, endb + amis, limit_v);
                 }
-                t.trailer_end_bit = br.bitpos();
+                t.trailer_end_bit = br.bitpos() - 8 * amis;
                 r.status = st.code;
                 r.detail = st.detail;
-                r.in_end_bit = br.bitpos();
+                r.in_end_bit = br.bitpos() - 8 * amis;
                 r.out_len = pos;
                 r.aux = aux;
                 results[u] = r;

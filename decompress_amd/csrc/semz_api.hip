@@ -28,6 +28,38 @@ int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...)
     return rc;
 }
 
+void semz_span_begin(semz_ctx *c, const char *name)
+{
+    if (!c->profile) return;
+    semz_ctx::span s{name, nullptr, nullptr};
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    (void)hipEventRecord(s.a, c->stream);
+    c->spans.push_back(s);
+}
+void semz_span_end(semz_ctx *c)
+{
+    if (!c->profile || c->spans.empty()) return;
+    (void)hipEventRecord(c->spans.back().b, c->stream);
+}
+
+// Per-kernel timing of the calls made since the last reset (profile option on).
+extern "C" int semz_profile_count(semz_ctx *c) { return c ? (int)c->spans.size() : 0; }
+extern "C" int semz_profile_get(semz_ctx *c, int i, const char **name, float *ms)
+{
+    if (!c || i < 0 || (size_t)i >= c->spans.size()) return -1;
+    auto &s = c->spans[i];
+    if (hipEventSynchronize(s.b) != hipSuccess) return -2;
+    if (hipEventElapsedTime(ms, s.a, s.b) != hipSuccess) return -2;
+    if (name) *name = s.name;
+    return 0;
+}
+extern "C" void semz_profile_reset(semz_ctx *c)
+{
+    if (!c) return;
+    for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    c->spans.clear();
+}
+
 extern "C" int semz_open(int device, semz_ctx **out)
 {
     if (!out) return -1;
@@ -55,6 +87,7 @@ extern "C" void semz_close(semz_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    semz_profile_reset(c);
     for (auto &b : c->bufs) if (b.p) hipFree(b.p);
     if (c->d_tabs) hipFree(c->d_tabs);
     hipStreamDestroy(c->stream);
@@ -71,6 +104,7 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
         c->inflate_group = (int)value;
         return 0;
     }
+    if (!strcmp(name, "profile")) { c->profile = value != 0; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
 }
 
@@ -107,10 +141,14 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
     case SEMZ_UNIT_DEFLATE:
     case SEMZ_UNIT_ZLIB:
     case SEMZ_UNIT_GZIP:
+        semz_span_begin(c, "inflate_kernel");
         semz_launch_inflate(c->inflate_group, (const uint8_t *)d_in, d_units, (uint32_t)nunits, (uint8_t *)d_out,
                             d_results, (semz_tail *)tails, c->stream);
+        semz_span_end(c);
+        semz_span_begin(c, "checksum_kernel");
         semz_launch_checksum((const uint8_t *)d_out, d_units, (uint32_t)nunits, d_results, (const semz_tail *)tails,
                              c->d_tabs, (1u << SEMZ_TK_CRC32) | (1u << SEMZ_TK_ADLER32), c->stream);
+        semz_span_end(c);
         break;
     case SEMZ_UNIT_BZIP2_BLOCK:
         rc = semz_run_bzip2(c, (const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,

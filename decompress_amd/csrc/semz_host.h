@@ -21,6 +21,10 @@ struct semz_ctx {
     semz_check_tables *d_tabs = nullptr;
     int inflate_group = 64;
     std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
+    // optional per-kernel timing (semz_set_option "profile"): event pairs on `stream`
+    bool profile = false;
+    struct span { const char *name; hipEvent_t a, b; };
+    std::vector<span> spans;
     char err[512] = {0};
 };
 
@@ -32,6 +36,9 @@ enum {
 };
 
 int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...);
+// RAII-less helpers: bracket a kernel (or kernel sequence) with events when profiling
+void semz_span_begin(semz_ctx *c, const char *name);
+void semz_span_end(semz_ctx *c);
 int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p);
 
 extern "C" {

@@ -129,8 +129,14 @@ int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
 int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
                              const semz_unit *d_units, size_t nunits,
                              void *d_out, size_t out_cap, semz_result *d_results);
-/* Tunables: "inflate_group" = lanes per deflate unit (16, 32 or 64). */
+/* Tunables: "inflate_group" = lanes per deflate unit (16, 32 or 64);
+ * "profile" = 1 records a HIP event pair around every kernel of later calls. */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
+/* Per-kernel device time of the calls since the last reset ("profile" on):
+ * spans come in launch order; *name is a static string. */
+int semz_profile_count(semz_ctx *ctx);
+int semz_profile_get(semz_ctx *ctx, int i, const char **name, float *ms);
+void semz_profile_reset(semz_ctx *ctx);
 int semz_sync(semz_ctx *ctx);
 /* The HIP stream the kernels run on (hipStream_t), for event timing. */
 void *semz_stream(semz_ctx *ctx);
