@@ -27,7 +27,7 @@ class Unit(C.Structure):
 class Result(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("detail", C.c_uint32),
-        ("in_end_bit", C.c_uint64), ("out_len", C.c_uint64),
+        ("in_end_bit", C.c_uint64), ("out_len", C.c_uint64), ("out_off", C.c_uint64),
         ("check", C.c_uint8 * 32), ("check_len", C.c_uint32), ("aux", C.c_uint32),
     ]
 
@@ -43,6 +43,8 @@ class StreamInfo(C.Structure):
 UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2 = range(6)
 FMT_DEFLATE, FMT_ZLIB, FMT_GZIP, FMT_BZIP2, FMT_RAW_LZMA, FMT_LZMA, FMT_RAW_LZMA2, FMT_LZMA2, FMT_XZ = range(9)
 UF_HAVE_DICT_FN, UF_BCJ_X86, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE, UF_DELTA = 1, 2, 4, 8, 16
+
+OUT_AUTO = 0xFFFFFFFFFFFFFFFF
 
 _lib = None
 

@@ -1,2 +1,732 @@
+// bzip2.hip -- gfx950 kernels for bzip2 blocks (one unit = one block).
+//
+// Replaces, per block, the reference loops
+//   parse-bzip2-block-header / selectors / trees   bzip2.lisp:298-395
+//   decode-bzip2-huffman+rle2                       bzip2.lisp:222-287
+//   decode-bzip2-mtf-in-place                       bzip2.lisp:175-191
+//   decode-bzip2-bwt                                bzip2.lisp:137-163
+//   derandomize-bzip2-block                         bzip2.lisp:112-121
+//   decode-bzip2-rle1 + block CRC                   bzip2.lisp:59-102, 507-524
+//
+// Kernel sequence (all device-resident, no host round trip):
+//   bz_decode_kernel  one wave per block: header, canonical trees in LDS, the
+//                     bit-serial Huffman+RLE2 decode with the inverse MTF fused
+//                     in (the 256-byte MTF stack lives in registers, 4 bytes per
+//                     lane, and is rotated with cross-lane moves)
+//   bz_bwt_kernel     one 1024-thread workgroup per block: byte histogram,
+//                     prefix sums, stable counting-sort scatter that builds the
+//                     merged (next << 8 | byte) vector, then the inverse-BWT walk
+//                     as 4096 concurrent chain segments (walk to measure, link
+//                     the segments in order, walk again to write), de-randomise,
+//                     and the sizing pass of RLE1
+//   bz_offsets_kernel exclusive scan of the block output sizes (SEMZ_OUT_AUTO)
+//   bz_rle1_kernel    RLE1 expansion into the final output span
+//   checksum_kernel   (checksums.hip) block CRC and its comparison
 #include "semz_host.h"
-int semz_run_bzip2(semz_ctx *c, const uint8_t *, size_t, const semz_unit *, uint32_t, uint8_t *, size_t, semz_result *, semz_tail *) { return semz_fail(c, -4, "bzip2 not built yet"); }
+
+namespace {
+
+constexpr uint32_t BZ_STRIDE = 900032;         // per-block scratch stride (bytes / entries)
+constexpr int BZ_ROOT_BITS = 9;
+constexpr int BZ_IN_CHUNK = 1024;              // input staging buffer (one aligned chunk)
+constexpr uint32_t BZ_SEL_STRIDE = 32768;
+constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:217-219
+constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
+constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
+
+struct bz_meta {
+    uint32_t n;            // bytes entering the inverse BWT
+    uint32_t orig;
+    uint32_t randomized;
+    uint32_t want_crc;
+    int32_t status;
+    uint32_t detail;
+    uint64_t end_bit;      // bit offset inside `in` after the block's end-of-block symbol
+    uint64_t out_len;      // bytes after RLE1
+    uint64_t out_off;
+};
+
+struct bz_seg {            // RLE1 entry state of one segment (bz_bwt_kernel -> bz_rle1_kernel)
+    uint32_t off;          // output offset of the segment inside the block's output
+    int16_t last;          // -1 = none
+    int16_t reps;
+};
+
+// bzip2's randtable.c (tables.lisp:85-149)
+__constant__ uint16_t BZ_RAND[512] = {
+ 619,720,127,481,931,816,813,233,566,247,985,724,205,454,863,491,741,242,949,214,
+ 733,859,335,708,621,574,73,654,730,472,419,436,278,496,867,210,399,680,480,51,
+ 878,465,811,169,869,675,611,697,867,561,862,687,507,283,482,129,807,591,733,623,
+ 150,238,59,379,684,877,625,169,643,105,170,607,520,932,727,476,693,425,174,647,
+ 73,122,335,530,442,853,695,249,445,515,909,545,703,919,874,474,882,500,594,612,
+ 641,801,220,162,819,984,589,513,495,799,161,604,958,533,221,400,386,867,600,782,
+ 382,596,414,171,516,375,682,485,911,276,98,553,163,354,666,933,424,341,533,870,
+ 227,730,475,186,263,647,537,686,600,224,469,68,770,919,190,373,294,822,808,206,
+ 184,943,795,384,383,461,404,758,839,887,715,67,618,276,204,918,873,777,604,560,
+ 951,160,578,722,79,804,96,409,713,940,652,934,970,447,318,353,859,672,112,785,
+ 645,863,803,350,139,93,354,99,820,908,609,772,154,274,580,184,79,626,630,742,
+ 653,282,762,623,680,81,927,626,789,125,411,521,938,300,821,78,343,175,128,250,
+ 170,774,972,275,999,639,495,78,352,126,857,956,358,619,580,124,737,594,701,612,
+ 669,112,134,694,363,992,809,743,168,974,944,375,748,52,600,747,642,182,862,81,
+ 344,805,988,739,511,655,814,334,249,515,897,955,664,981,649,113,974,459,893,228,
+ 433,837,553,268,926,240,102,654,459,51,686,754,806,760,493,403,415,394,687,700,
+ 946,670,656,610,738,392,760,799,887,653,978,321,576,617,626,502,894,679,243,440,
+ 680,879,194,572,640,724,926,56,204,700,707,151,457,449,797,195,791,558,945,679,
+ 297,59,87,824,713,663,412,693,342,606,134,108,571,364,631,212,174,643,304,329,
+ 343,97,430,751,497,314,983,374,822,928,140,206,73,263,980,736,876,478,430,305,
+ 170,514,364,692,829,82,855,953,676,246,369,970,294,750,807,827,150,790,288,923,
+ 804,378,215,828,592,281,565,555,710,82,896,831,547,261,524,462,293,465,502,56,
+ 661,821,976,991,658,869,905,758,745,193,768,550,608,933,378,286,215,979,792,961,
+ 61,688,793,644,986,403,106,366,905,644,372,567,466,434,645,210,389,550,919,135,
+ 780,773,635,389,707,100,626,958,165,504,920,176,193,713,857,265,203,50,668,108,
+ 645,990,626,197,510,357,358,850,858,364,936,638 };
+
+struct BzTree {
+    uint16_t root[1 << BZ_ROOT_BITS];   // (symbol << 4) | length, 0 = code longer than the root
+    uint16_t sorted[260];
+    uint32_t limit[21];                  // (first+count) << (20-len)
+    uint16_t first[21];
+    uint16_t offs[21];
+    uint32_t maxlen;
+};
+
+struct __align__(16) BzLds {
+    uint8_t inbuf[BZ_IN_CHUNK];
+    BzTree tree[6];
+    uint8_t lens[260];
+    uint8_t symbols[256];
+    uint16_t count[32];
+    int32_t status;
+};
+
+// MSB-first bit reader (msb-bit-reader, bits.lisp:121).  Every lane of the
+// wave holds the same state; the staging buffer is refilled cooperatively
+// (64 lanes x 16 bytes) whenever the reader crosses a chunk boundary.
+struct MsbReader {
+    const uint8_t *in_v0;   // in_v0 + v = address of v-offset v (see inflate.hip)
+    uint8_t *buf_lds;
+    uint64_t in_lo, limit;  // valid v-offsets are [in_lo, limit)
+    uint64_t wpos;          // v-offset of the next dword
+    uint64_t s_hi;          // staged chunk is [s_hi - BZ_IN_CHUNK, s_hi)
+    uint64_t buf;           // bits left aligned: next bit is bit 63
+    int cnt;
+    bool near_end;
+
+    __device__ void stage()
+    {
+        // all 64 lanes: load the chunk that starts at wpos (1 KiB aligned in v-space)
+        const int lane = threadIdx.x & 63;
+        const uint64_t base = wpos & ~(uint64_t)(BZ_IN_CHUNK - 1);
+        const uint64_t v = base + 16u * lane;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (v >= in_lo && v + 16 <= limit) x = *reinterpret_cast<const uint4 *>(in_v0 + v);
+        else if (v < limit && v + 16 > in_lo) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 16; b++) {
+                uint64_t vv = v + b;
+                if (vv >= in_lo && vv < limit) w[b >> 2] |= (uint32_t)in_v0[vv] << (8 * (b & 3));
+            }
+            x = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        lds_sync();
+        *reinterpret_cast<uint4 *>(buf_lds + 16 * lane) = x;
+        lds_sync();
+        s_hi = base + BZ_IN_CHUNK;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (cnt <= 32) {
+            if (wpos >= s_hi) stage();
+            uint32_t w = *reinterpret_cast<const uint32_t *>(buf_lds + (wpos & (BZ_IN_CHUNK - 1)));
+            w = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bswap32(w));
+            if (wpos + 4 > limit) near_end = true;
+            wpos += 4;
+            buf |= (uint64_t)w << (32 - cnt);
+            cnt += 32;
+        }
+    }
+    __device__ void init(const uint8_t *v0, uint8_t *lds, uint64_t lo, uint64_t lim, uint64_t v, uint32_t bit_off)
+    {
+        in_v0 = v0; buf_lds = lds; in_lo = lo; limit = lim;
+        wpos = v & ~3ull; s_hi = 0; buf = 0; cnt = 0; near_end = false;
+        // position of the first bit inside the first dword
+        int skip = (int)(v & 3) * 8 + (int)bit_off;
+        s_hi = 0;
+        stage();
+        refill();
+        buf <<= skip;
+        cnt -= skip;
+    }
+    __device__ __forceinline__ int64_t remaining() const { return (int64_t)(8 * limit) - (int64_t)(8 * wpos) + cnt; }
+    __device__ __forceinline__ bool short_of(int n) const { return near_end && remaining() < n; }
+    __device__ __forceinline__ uint64_t bitpos() const { return 8 * wpos - (uint64_t)cnt; }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf >> (64 - n)); }
+    __device__ __forceinline__ void drop(int n) { buf <<= n; cnt -= n; }
+    // read n <= 24 bits; sets eof instead of reading past the end
+    __device__ __forceinline__ uint32_t read(int n, bool &eof)
+    {
+        refill();
+        if (short_of(n)) { eof = true; return 0; }
+        uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+};
+
+// One canonical tree from lens[0..n) (lengths->ht :be, huffman.lisp:142-225).
+__device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t c = 0;
+    if (lane >= 1 && lane <= 20)
+        for (int s = 0; s < n; s++) c += (L.lens[s] == lane);
+    if (lane < 32) L.count[lane] = (uint16_t)c;
+    lds_sync();
+    if (lane == 0) {
+        uint32_t code = 0, off = 0, total = 0, maxl = 1;
+        T.first[0] = 0; T.offs[0] = 0; T.limit[0] = 0;
+        for (int l = 1; l <= 20; l++) {
+            uint32_t cnt = L.count[l];
+            code <<= 1;
+            T.first[l] = (uint16_t)code;
+            T.offs[l] = (uint16_t)off;
+            code += cnt;
+            off += cnt;
+            T.limit[l] = code << (20 - l);
+            total += cnt << (20 - l);
+            if (cnt) maxl = l;
+        }
+        T.maxlen = maxl;
+        L.status = total < (1u << 20) ? SEMZ_E_HUFF_UNDERFULL : total > (1u << 20) ? SEMZ_E_HUFF_OVERFULL : SEMZ_OK;
+    }
+    lds_sync();
+    int st = L.status;
+    if (st != SEMZ_OK) return st;
+    if (lane >= 1 && lane <= 20) {
+        uint32_t k = T.offs[lane];
+        for (int s = 0; s < n; s++)
+            if (L.lens[s] == lane) T.sorted[k++] = (uint16_t)s;
+    }
+    lds_sync();
+    for (int i = lane; i < (1 << BZ_ROOT_BITS); i += 64) {
+        uint32_t v20 = (uint32_t)i << (20 - BZ_ROOT_BITS);
+        uint16_t e = 0;
+        for (int l = 1; l <= BZ_ROOT_BITS; l++) {
+            if (v20 < T.limit[l]) {
+                uint32_t idx = T.offs[l] + (v20 >> (20 - l)) - T.first[l];
+                e = (uint16_t)((T.sorted[idx] << 4) | l);
+                break;
+            }
+        }
+        T.root[i] = e;
+    }
+    lds_sync();
+    return SEMZ_OK;
+}
+
+__global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
+                                                       bz_meta *meta, uint8_t *pre_all, uint8_t *sel_all)
+{
+    __shared__ BzLds L;
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const int lane = threadIdx.x & 63;
+    const semz_unit un = units[u];
+    uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
+    uint8_t *sel = sel_all + (size_t)u * BZ_SEL_STRIDE;
+    const uint32_t level = un.param0 >= 1 && un.param0 <= 9 ? un.param0 : 9;
+    const uint32_t block_size = level * 100000u;
+
+    const uint64_t amis = (uint64_t)((uintptr_t)in & 15);
+    MsbReader br;
+    br.init(in - amis, L.inbuf, amis, un.in_limit + amis, un.in_off + amis, un.in_bit_off);
+
+    int status = SEMZ_OK;
+    uint32_t detail = 0;
+    bool eof = false;
+    uint32_t n = 0, orig = 0, randomized = 0, want_crc = 0;
+#define BZ_FAIL(code, det) do { status = (code); detail = (det); goto done; } while (0)
+#define BZ_EOFCHK() do { if (eof) BZ_FAIL(SEMZ_EOF, 0); } while (0)
+    {
+        // 48-bit block magic (bzip2.lisp:460-463)
+        uint32_t m1 = br.read(24, eof); BZ_EOFCHK();
+        uint32_t m2 = br.read(24, eof); BZ_EOFCHK();
+        if (m1 != 0x314159u || m2 != 0x265359u) BZ_FAIL(SEMZ_E_BZ_BLOCK_MAGIC, 0);
+        // parse-bzip2-block-header, bzip2.lisp:351-395
+        uint32_t c1 = br.read(16, eof); BZ_EOFCHK();
+        uint32_t c2 = br.read(16, eof); BZ_EOFCHK();
+        want_crc = (c1 << 16) | c2;
+        randomized = br.read(1, eof); BZ_EOFCHK();
+        orig = br.read(24, eof); BZ_EOFCHK();
+        uint32_t l1 = br.read(16, eof); BZ_EOFCHK();
+        if (l1 == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 0);
+        uint32_t nsym = 0;
+        for (int i = 0; i < 16; i++) {
+            if (!((l1 >> (15 - i)) & 1)) continue;
+            uint32_t l2 = br.read(16, eof); BZ_EOFCHK();
+            for (int j = 0; j < 16; j++)
+                if ((l2 >> (15 - j)) & 1) {
+                    if (lane == 0) L.symbols[nsym] = (uint8_t)(16 * i + j);
+                    nsym++;
+                }
+        }
+        uint32_t ntrees = br.read(3, eof); BZ_EOFCHK();
+        uint32_t nsel = br.read(15, eof); BZ_EOFCHK();
+        if (ntrees < 2 || ntrees > 6) BZ_FAIL(SEMZ_E_BZ_TREE_COUNT, ntrees);
+        if (nsel == 0) BZ_FAIL(SEMZ_E_BZ_NO_SELECTORS, 0);
+        // read-bzip2-selectors (bzip2.lisp:302-311): codes 0,10,110,1110,11110,111110,111111, then MTF
+        {
+            uint32_t stack = 0x543210u;                 // nibble j = tree at MTF position j
+            for (uint32_t i = 0; i < nsel; i++) {
+                br.refill();
+                if (br.short_of(6)) BZ_FAIL(SEMZ_EOF, 0);
+                uint32_t six = br.peek(6);
+                uint32_t idx = (uint32_t)__builtin_clz(~(six << 26));   // leading ones
+                if (idx > 6) idx = 6;
+                br.drop(idx < 6 ? idx + 1 : 6);
+                if (idx >= ntrees) BZ_FAIL(SEMZ_E_BZ_SELECTOR, idx);
+                uint32_t val = (stack >> (4 * idx)) & 15;
+                uint32_t low = stack & ((1u << (4 * idx)) - 1);
+                uint32_t high = idx >= 7 ? 0 : (stack >> (4 * (idx + 1))) << (4 * (idx + 1));
+                stack = high | (low << 4) | val;
+                if (lane == 0) sel[i] = (uint8_t)val;
+            }
+            __threadfence_block();                      // sel[] is read back from memory below
+        }
+        // read-bzip2-trees (bzip2.lisp:317-343): 5-bit start, then 0 = emit, 10 = +1, 11 = -1
+        for (uint32_t t = 0; t < ntrees; t++) {
+            int cur = (int)br.read(5, eof); BZ_EOFCHK();
+            for (uint32_t i = 0; i < nsym + 2; i++) {
+                for (;;) {
+                    if (cur < 1 || cur > 20) BZ_FAIL(SEMZ_E_BZ_CODELEN, 0);
+                    br.refill();
+                    if (br.short_of(2)) BZ_FAIL(SEMZ_EOF, 0);
+                    uint32_t two = br.peek(2);
+                    if (two < 2) { br.drop(1); break; }
+                    br.drop(2);
+                    cur += two == 2 ? 1 : -1;
+                }
+                if (lane == 0) L.lens[i] = (uint8_t)cur;
+            }
+            lds_sync();
+            int ts = bz_build_tree(L, L.tree[t], (int)nsym + 2);
+            if (ts != SEMZ_OK) BZ_FAIL(ts, 0);
+        }
+        if (nsym == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 1);
+        lds_sync();
+
+        // inverse-MTF stack: lane i holds entries 4i .. 4i+3 (byte j of the word = entry 4i+j)
+        uint32_t w = 0;
+        for (int j = 0; j < 4; j++) {
+            uint32_t k = 4 * lane + j;
+            if (k < nsym) w |= (uint32_t)L.symbols[k] << (8 * j);
+        }
+
+        // decode-bzip2-huffman+rle2 fused with decode-bzip2-mtf-in-place
+        const uint32_t eob = nsym + 1;
+        uint32_t ab_len = 0, ab_val = 0;
+        bool finished = false;
+        for (uint32_t g = 0; !finished; g++) {
+            if (g >= nsel) BZ_FAIL(SEMZ_E_BZ_SELECTORS_EXHAUSTED, 0);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel[g]);
+            const BzTree &T = L.tree[t];
+            const int maxlen = (int)T.maxlen;
+            for (int k = 0; k < 50; k++) {
+                br.refill();
+                uint32_t e = T.root[br.peek(BZ_ROOT_BITS)];
+                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+                uint32_t len = e & 15, sym = e >> 4;
+                if (len == 0) {
+                    uint32_t v20 = br.peek(20);
+                    for (int l = BZ_ROOT_BITS + 1; l <= 20; l++) {
+                        if (v20 < T.limit[l]) {
+                            sym = T.sorted[T.offs[l] + (v20 >> (20 - l)) - T.first[l]];
+                            len = l;
+                            break;
+                        }
+                    }
+                    sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
+                    len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+                }
+                if (br.short_of(maxlen)) BZ_FAIL(SEMZ_EOF, 0);      // trees are always full-read (80 trailing bits)
+                br.drop(len);
+                if (sym < 2) {
+                    if (ab_len >= (uint32_t)BZ_AB_BOUND) BZ_FAIL(SEMZ_E_BZ_AB_RUN_LENGTH, 0);
+                    ab_val |= sym << ab_len;
+                    ab_len++;
+                    continue;
+                }
+                if (ab_len) {
+                    uint32_t run = (ab_val | (1u << ab_len)) - 1;
+                    if (n + run > block_size) BZ_FAIL(SEMZ_E_BZ_AB_RUN_SIZE, 0);
+                    uint8_t front = (uint8_t)__builtin_amdgcn_readfirstlane((int)(w & 0xFF));
+                    for (uint32_t i = lane; i < run; i += 64) pre[n + i] = front;
+                    n += run;
+                    ab_len = 0;
+                    ab_val = 0;
+                }
+                if (sym == eob) { finished = true; break; }
+                if (n >= block_size) BZ_FAIL(SEMZ_E_BZ_TOO_MANY_CODES, 0);
+                // move-to-front of entry idx
+                uint32_t idx = sym - 1, q = idx >> 2, r = idx & 3;
+                uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)q);
+                uint32_t x = (wq >> (8 * r)) & 0xFF;
+                if (idx) {
+                    uint32_t prev = (uint32_t)__shfl_up((int)w, 1, 64);
+                    uint32_t shifted = (w << 8) | (lane == 0 ? x : prev >> 24);
+                    if ((uint32_t)lane < q) w = shifted;
+                    else if ((uint32_t)lane == q) {
+                        uint32_t mask = r == 3 ? 0xFFFFFFFFu : (1u << (8 * (r + 1))) - 1;
+                        w = (shifted & mask) | (w & ~mask);
+                    }
+                }
+                if (lane == 0) pre[n] = (uint8_t)x;
+                n++;
+            }
+        }
+        // decode-bzip2-bwt's precondition; deliberate divergence, see DESIGN.md
+        if (n == 0 ? orig >= block_size : orig >= n) BZ_FAIL(SEMZ_E_BZ_ORIGPTR, orig);
+    }
+done:
+    if (lane == 0) {
+        bz_meta m;
+        m.n = n; m.orig = orig; m.randomized = randomized; m.want_crc = want_crc;
+        m.status = status; m.detail = detail;
+        m.end_bit = br.bitpos() - 8 * amis;
+        m.out_len = 0; m.out_off = 0;
+        meta[u] = m;
+    }
+#undef BZ_FAIL
+#undef BZ_EOFCHK
+}
+
+// ---- RLE1 state machine (decode-bzip2-rle1, bzip2.lisp:59-102) ----
+struct Rle1 { int last; int reps; };
+// consumes one post-BWT byte; returns how many output bytes it produces and which byte
+__device__ __forceinline__ uint32_t rle1_step(Rle1 &s, uint32_t b, uint32_t &outbyte)
+{
+    if (s.reps < 3) {
+        s.reps = ((int)b == s.last) ? s.reps + 1 : 0;
+        s.last = (int)b;
+        outbyte = b;
+        return 1;
+    }
+    outbyte = (uint32_t)s.last;
+    s.last = -1;
+    s.reps = 0;
+    return b;
+}
+
+__global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *meta, const uint8_t *pre_all,
+                                                      uint32_t *tt_all, uint8_t *post_all, bz_seg *seg_all)
+{
+    extern __shared__ __align__(16) uint32_t smem[];
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const bz_meta m = meta[u];
+    if (m.status != SEMZ_OK) return;
+    const uint32_t n = m.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
+    uint32_t *tt = tt_all + (size_t)u * BZ_STRIDE;
+    uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
+    bz_seg *segs = seg_all + (size_t)u * BZ_SEGS;
+
+    // ---- 1. per-wave byte histograms ----
+    uint32_t *hist = smem;                         // [16][256]
+    uint32_t *cumm = smem + 16 * 256;              // [256]
+    for (uint32_t i = tid; i < 16 * 256 + 256; i += 1024) smem[i] = 0;
+    __syncthreads();
+    const uint32_t chunk = (((n + 15) / 16) + 63) & ~63u;
+    const uint32_t cbeg = wave * chunk, cend = cbeg + chunk < n ? cbeg + chunk : n;
+    for (uint32_t i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + pre[i]], 1u);
+    __syncthreads();
+    // ---- 2. prefix sums: cumm[v] (bzip2.lisp:150-151) and each wave's base per byte value ----
+    if (tid < 256) {
+        uint32_t total = 0;
+        for (int w = 0; w < 16; w++) { uint32_t t = hist[w * 256 + tid]; hist[w * 256 + tid] = total; total += t; }
+        cumm[tid] = total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int v = 0; v < 256; v++) { uint32_t t = cumm[v]; cumm[v] = acc; acc += t; }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < 16 * 256; i += 1024) hist[i] += cumm[i & 255];
+    __syncthreads();
+    // ---- 3. stable scatter: tt[cumm[v]++] = (i << 8) | v  (bzip2.lisp:153-156) ----
+    for (uint32_t b0 = cbeg; b0 < cend; b0 += 64) {
+        const uint32_t i = b0 + lane;
+        const bool valid = i < cend;
+        const uint32_t v = valid ? pre[i] : 0;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+            uint64_t bm = __ballot((v >> bit) & 1);
+            same &= ((v >> bit) & 1) ? bm : ~bm;
+        }
+        const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
+        const uint32_t cnt = __popcll(same);
+        uint32_t old = 0;
+        if (valid) old = hist[wave * 256 + v];
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            tt[old + rank] = (i << 8) | v;
+            if (rank == 0) hist[wave * 256 + v] = old + cnt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 4. inverse BWT walk (bzip2.lisp:158-163) as chain segments ----
+    // out[j] = low byte of tt[k_j], k_0 = origPtr, k_{j+1} = tt[k_j] >> 8.
+    // Markers: k = origPtr (id 0) and k = j*S (id j+1).  Every marker walks until it meets a marker.
+    uint32_t *seg_len = smem;                      // [BZ_CHAINS + 1]
+    uint32_t *seg_next = smem + (BZ_CHAINS + 1);
+    uint32_t *seg_off = smem + 2 * (BZ_CHAINS + 1);
+    uint32_t *misc = smem + 3 * (BZ_CHAINS + 1);   // [0] = cycle length
+    uint32_t S = 1;
+    while ((uint64_t)S * BZ_CHAINS < n) S <<= 1;
+    const uint32_t nreg = n ? (n + S - 1) / S : 0; // regular markers 0, S, 2S, ...
+    const uint32_t nmark = nreg + 1;
+    const uint32_t orig = m.orig;
+    for (uint32_t i = tid; i < nmark; i += 1024) seg_off[i] = 0xFFFFFFFFu;
+    if (n) {
+        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * 1024) {
+            uint32_t k[4], len[4];
+            bool act[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t id = id0 + c * 1024;
+                act[c] = id < nmark;
+                k[c] = id == 0 ? orig : (id - 1) * S;
+                len[c] = 0;
+            }
+            bool any = true;
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (!act[c]) continue;
+                    uint32_t nk = tt[k[c]] >> 8;
+                    len[c]++;
+                    k[c] = nk;
+                    if (nk == orig || (nk & (S - 1)) == 0) act[c] = false;
+                    else any = true;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t id = id0 + c * 1024;
+                if (id < nmark) {
+                    seg_len[id] = len[c];
+                    seg_next[id] = k[c] == orig ? 0 : k[c] / S + 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t t = 0, off = 0;
+        while (off < n && seg_off[t] == 0xFFFFFFFFu) {
+            seg_off[t] = off;
+            off += seg_len[t];
+            t = seg_next[t];
+        }
+        misc[0] = off;                              // >= n, or the length of origPtr's cycle if shorter
+    }
+    __syncthreads();
+    const uint32_t cyc = misc[0];
+    const uint32_t wlim = cyc < n ? cyc : n;
+    if (n) {
+        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * 1024) {
+            uint32_t k[4], o[4], e[4];
+            bool act[4];
+            bool any = false;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t id = id0 + c * 1024;
+                act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu;
+                k[c] = id == 0 ? orig : (id - 1) * S;
+                o[c] = act[c] ? seg_off[id] : 0;
+                e[c] = act[c] ? o[c] + seg_len[id] : 0;
+                any = any || act[c];
+            }
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (!act[c]) continue;
+                    uint32_t v = tt[k[c]];
+                    if (o[c] < wlim) post[o[c]] = (uint8_t)v;
+                    k[c] = v >> 8;
+                    o[c]++;
+                    if (o[c] >= e[c]) act[c] = false;
+                    else any = true;
+                }
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (cyc < n) {
+        // origPtr's cycle is shorter than the block: the output is periodic
+        for (uint32_t j = cyc + tid; j < n; j += 1024) post[j] = post[j % cyc];
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ---- 5. de-randomise (bzip2.lisp:112-121) ----
+    if (m.randomized && tid == 0) {
+        uint32_t di = 0;
+        for (uint32_t ri = 0;; ri++) {
+            uint32_t skip = BZ_RAND[ri & 511];
+            di = ri == 0 ? skip - 2 : di + skip;
+            if (di >= n) break;
+            post[di] ^= 1;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- 6. RLE1 sizing: every thread parses its segment from each of the five
+    //         possible entry classes; thread 0 then chains the real states ----
+    // classes: 0 fresh (last != first byte, reps < 3), 1 count byte expected (reps == 3),
+    //          2..4 last == first byte with reps 0..2
+    uint32_t *r_len = smem;                         // [BZ_SEGS][5]
+    uint32_t *r_exit = smem + BZ_SEGS * 5;          // [BZ_SEGS][5]  (last+1) << 2 | reps
+    const uint32_t seglen = (n + BZ_SEGS - 1) / BZ_SEGS;
+    const uint32_t sbeg = tid * seglen < n ? tid * seglen : n;
+    const uint32_t send = sbeg + seglen < n ? sbeg + seglen : n;
+    {
+        const int first = sbeg < send ? post[sbeg] : -1;
+        Rle1 st[5] = {{-1, 0}, {first, 3}, {first, 0}, {first, 1}, {first, 2}};
+        uint32_t ol[5] = {0, 0, 0, 0, 0};
+        for (uint32_t i = sbeg; i < send; i++) {
+            uint32_t b = post[i], ob;
+#pragma unroll
+            for (int c = 0; c < 5; c++) ol[c] += rle1_step(st[c], b, ob);
+        }
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            r_len[tid * 5 + c] = ol[c];
+            r_exit[tid * 5 + c] = ((uint32_t)(st[c].last + 1) << 2) | (uint32_t)st[c].reps;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        Rle1 st = {-1, 0};
+        uint64_t off = 0;
+        for (uint32_t s = 0; s < BZ_SEGS; s++) {
+            uint32_t b0 = s * seglen < n ? s * seglen : n;
+            bz_seg g;
+            g.off = (uint32_t)off;
+            g.last = (int16_t)st.last;
+            g.reps = (int16_t)st.reps;
+            segs[s] = g;
+            if (b0 >= n) continue;
+            int first = post[b0];
+            int cls = st.reps == 3 ? 1 : (st.last == first ? 2 + st.reps : 0);
+            off += r_len[s * 5 + cls];
+            uint32_t ex = r_exit[s * 5 + cls];
+            // class 1 with a one-byte segment keeps no history; other exits are self-contained
+            st.last = (int)(ex >> 2) - 1;
+            st.reps = (int)(ex & 3);
+        }
+        meta[u].out_len = off;
+    }
+}
+
+// Exclusive scan of the block sizes for SEMZ_OUT_AUTO units, capacity checks, results and tails.
+__global__ void bz_offsets_kernel(const semz_unit *units, uint32_t nunits, bz_meta *meta, uint64_t out_cap,
+                                  semz_result *results, semz_tail *tails)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint64_t auto_off = 0;
+    for (uint32_t u = 0; u < nunits; u++) {
+        bz_meta m = meta[u];
+        semz_result r{};
+        semz_tail t{};
+        r.status = m.status;
+        r.detail = m.detail;
+        r.in_end_bit = m.end_bit;
+        if (m.status == SEMZ_OK) {
+            uint64_t off, cap;
+            if (units[u].out_off == SEMZ_OUT_AUTO) { off = auto_off; cap = out_cap > off ? out_cap - off : 0; auto_off += m.out_len; }
+            else { off = units[u].out_off; cap = units[u].out_cap; }
+            if (m.out_len > cap) { r.status = SEMZ_E_OUT_CAP; m.status = SEMZ_E_OUT_CAP; }
+            m.out_off = off;
+            r.out_off = off;
+            r.out_len = m.status == SEMZ_OK ? m.out_len : 0;
+            t.check_kind = SEMZ_TK_BZCRC;
+            t.want[0] = m.want_crc;
+            t.have_check = 1;
+            meta[u] = m;
+        }
+        results[u] = r;
+        tails[u] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void bz_rle1_kernel(uint32_t nunits, const bz_meta *meta, const uint8_t *post_all,
+                                                       const bz_seg *seg_all, uint8_t *out)
+{
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const bz_meta m = meta[u];
+    if (m.status != SEMZ_OK) return;
+    const uint32_t n = m.n, tid = threadIdx.x;
+    const uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
+    const bz_seg g = seg_all[(size_t)u * BZ_SEGS + tid];
+    uint8_t *o = out + m.out_off + g.off;
+    const uint32_t seglen = (n + BZ_SEGS - 1) / BZ_SEGS;
+    const uint32_t sbeg = tid * seglen < n ? tid * seglen : n;
+    const uint32_t send = sbeg + seglen < n ? sbeg + seglen : n;
+    Rle1 st = {g.last, g.reps};
+    for (uint32_t i = sbeg; i < send; i++) {
+        uint32_t ob, k = rle1_step(st, post[i], ob);
+        for (uint32_t j = 0; j < k; j++) o[j] = (uint8_t)ob;
+        o += k;
+    }
+}
+
+} // namespace
+
+int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
+{
+    (void)in_len;
+    void *meta, *pre, *post, *tt, *sel, *segs;
+    int rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_META, (size_t)nunits * sizeof(bz_meta), &meta))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_DATA, (size_t)nunits * BZ_STRIDE * 2, &pre))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_TT, (size_t)nunits * BZ_STRIDE * sizeof(uint32_t), &tt))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * (BZ_SEL_STRIDE + BZ_SEGS * sizeof(bz_seg)), &sel))) return rc;
+    post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
+    segs = (uint8_t *)sel + (size_t)nunits * BZ_SEL_STRIDE;
+    const size_t smem = (3 * (BZ_CHAINS + 1) + 16) * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)bz_bwt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return semz_fail(c, -2, "cannot reserve %zu bytes of LDS for bz_bwt_kernel", smem);
+        attr_set = true;
+    }
+    semz_span_begin(c, "bz_decode_kernel");
+    bz_decode_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)sel);
+    semz_span_end(c);
+    semz_span_begin(c, "bz_bwt_kernel");
+    bz_bwt_kernel<<<nunits, 1024, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,
+                                                     (uint8_t *)post, (bz_seg *)segs);
+    semz_span_end(c);
+    semz_span_begin(c, "bz_offsets_kernel");
+    bz_offsets_kernel<<<1, 64, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);
+    semz_span_end(c);
+    semz_span_begin(c, "bz_rle1_kernel");
+    bz_rle1_kernel<<<nunits, 1024, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint8_t *)post,
+                                                   (const bz_seg *)segs, d_out);
+    semz_span_end(c);
+    semz_span_begin(c, "checksum_kernel");
+    semz_launch_checksum(d_out, d_units, nunits, d_results, d_tails, c->d_tabs, 1u << SEMZ_TK_BZCRC, c->stream);
+    semz_span_end(c);
+    return 0;
+}

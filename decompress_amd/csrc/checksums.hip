@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
     semz_result r = results[u];
     const semz_tail t = tails[u];
     if (r.status != SEMZ_OK) return;
-    const uint8_t *p = out + units[u].out_off;
+    const uint8_t *p = out + r.out_off;
     const uint64_t n = r.out_len;
     const uint32_t a = (uint32_t)((uintptr_t)p & 15);
     const Seg g = lane_segment(n, a, lane);

@@ -732,6 +732,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *in, const se
                 r.detail = st.detail;
                 r.in_end_bit = br.bitpos() - 8 * amis;
                 r.out_len = pos;
+                r.out_off = un.out_off;
                 r.aux = aux;
                 results[u] = r;
                 tails[u] = t;

@@ -191,6 +191,12 @@ extern "C" int semz_decode_batch(semz_ctx *c, const uint8_t *in, size_t in_len, 
         uint32_t f = u.kind <= SEMZ_UNIT_GZIP ? 0 : u.kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : 2;
         if (u.kind > SEMZ_UNIT_LZMA2 || f != fam) return semz_fail(c, -1, "unit %zu: mixed or unknown kind", i);
         if (u.in_off > u.in_limit || u.in_limit > in_len) return semz_fail(c, -1, "unit %zu: input span out of range", i);
+        if (u.in_bit_off > 7) return semz_fail(c, -1, "unit %zu: bit offset", i);
+        if (u.out_off == SEMZ_OUT_AUTO) {
+            if (u.kind != SEMZ_UNIT_BZIP2_BLOCK) return semz_fail(c, -1, "unit %zu: SEMZ_OUT_AUTO is for bzip2 blocks", i);
+            out_hi = out_cap;
+            continue;
+        }
         if (u.out_off > out_cap || u.out_cap > out_cap - u.out_off) return semz_fail(c, -1, "unit %zu: output span out of range", i);
         if (u.prefix_len && (u.prefix_off > in_len || u.prefix_len > in_len - u.prefix_off))
             return semz_fail(c, -1, "unit %zu: prefix span out of range", i);

@@ -67,13 +67,19 @@ enum {
 /* xz check types (xz.lisp:12-31) */
 enum { SEMZ_CHECK_NONE = 0, SEMZ_CHECK_CRC32 = 1, SEMZ_CHECK_CRC64 = 4, SEMZ_CHECK_SHA256 = 10 };
 
+#define SEMZ_OUT_AUTO UINT64_MAX
+
 typedef struct semz_unit {
     uint64_t in_off;      /* byte offset of the unit inside `in` */
     uint64_t in_limit;    /* one past the last byte this unit may read: reads beyond are
                              `eof` (io.lisp:93-104).  In all-members mode this is the end of
                              the input, because the reference's bit readers may look ahead
                              into the next member (interface.lisp:81-84). */
-    uint64_t out_off;     /* byte offset of the unit's output inside `out` */
+    uint64_t out_off;     /* byte offset of the unit's output inside `out`, or SEMZ_OUT_AUTO
+                             (bzip2 blocks only): the engine packs the outputs of the batch
+                             back to back in unit order and reports each offset in
+                             semz_result.out_off; out_cap is then ignored per unit and the
+                             call's out_cap bounds the whole batch */
     uint64_t out_cap;     /* bytes available at out_off; exceeding it is SEMZ_E_OUT_CAP */
     uint32_t kind;        /* SEMZ_UNIT_* */
     uint32_t flags;       /* SEMZ_UF_* */
@@ -95,6 +101,7 @@ typedef struct semz_result {
     uint64_t in_end_bit;  /* bit offset inside `in` one past the last bit the unit consumed,
                              trailer included: unit k+1 starts at ceil(in_end_bit / 8) */
     uint64_t out_len;     /* bytes written at out_off */
+    uint64_t out_off;     /* where the output was written (== unit.out_off unless SEMZ_OUT_AUTO) */
     uint8_t  check[32];   /* computed checksum as the little-endian byte string the reference
                              compares (crc32/adler32/bzip2 crc: 4, crc64: 8, sha256: 32) */
     uint32_t check_len;

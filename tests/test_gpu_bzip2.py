@@ -1,0 +1,126 @@
+"""GPU parity: bzip2 blocks through the C ABI vs the CPU oracle (bit-exact)."""
+import bz2
+import random
+
+import numpy as np
+import pytest
+
+import corpus
+from decompress_amd import _lib
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+BLOCK_MAGIC = 0x314159265359
+FOOTER_MAGIC = 0x177245385090
+
+
+def find_magic(data, magic):
+    """Bit offsets of a 48-bit magic (test-side scan; the product has its own in split.cpp)."""
+    bits = np.unpackbits(np.frombuffer(data, dtype=np.uint8))
+    pat = np.unpackbits(np.frombuffer(magic.to_bytes(6, "big"), dtype=np.uint8))
+    if bits.size < 48:
+        return []
+    acc = np.ones(bits.size - 47, dtype=bool)
+    for k in range(48):
+        acc &= bits[k:bits.size - 47 + k] == pat[k]
+    return [int(p) for p in np.nonzero(acc)[0]]
+
+
+def block_units(data, level, auto=True, caps=None):
+    units = []
+    for i, p in enumerate(find_magic(data, BLOCK_MAGIC)):
+        units.append(_lib.Unit(in_off=p // 8, in_bit_off=p % 8, in_limit=len(data),
+                               out_off=_lib.OUT_AUTO if auto else caps[i][0],
+                               out_cap=0 if auto else caps[i][1],
+                               kind=_lib.UNIT_BZIP2_BLOCK, param0=level))
+    return units
+
+
+def check_stream(engine, data, level, expect=None, cap=None):
+    units = block_units(data, level)
+    assert units
+    cap = cap if cap is not None else (len(expect) if expect is not None else 1 << 22)
+    out, res = engine.decode_batch(data, units, cap)
+    total = b""
+    for u, r in zip(units, res):
+        er, eo = oracle.bzip2_block(data, 8 * u.in_off + u.in_bit_off, level, cap=max(cap, 1))
+        assert r.status == er.status, (r.status, er.status, r.detail, er.detail)
+        if er.status == 0:
+            assert r.in_end_bit == er.in_end_bit
+            assert out.raw[r.out_off:r.out_off + r.out_len] == eo
+            assert bytes(r.check[:4]) == bytes(er.check[:4])
+            total += eo
+        else:
+            assert r.detail == er.detail
+    if expect is not None:
+        assert total == expect
+    return res
+
+
+@pytest.mark.parametrize("level", [1, 9])
+def test_valid_blocks(engine, level):
+    random.seed(level)
+    for i, n in enumerate([1, 5, 300, 5000, 100000, 250000]):
+        for gen in (corpus.text, corpus.random_bytes, corpus.repetitive, corpus.mixed):
+            d = gen(n, seed=100 * i + level)
+            check_stream(engine, bz2.compress(d, level), level, d)
+
+
+def test_full_size_blocks(engine):
+    d = corpus.text(2_000_000, seed=77)
+    check_stream(engine, bz2.compress(d, 9), 9, d)
+    z = bytes(3_000_000)                      # periodic block contents: short inverse-BWT cycles
+    check_stream(engine, bz2.compress(z, 9), 9, z)
+    r = corpus.repetitive(1_500_000, seed=5)  # long RLE1 runs
+    check_stream(engine, bz2.compress(r, 9), 9, r)
+
+
+def test_multistream_batch(engine):
+    parts = [corpus.text(120000, seed=1), corpus.mixed(40000, seed=2), corpus.random_bytes(7000, seed=3)]
+    data = b"".join(bz2.compress(p, 1) for p in parts)
+    check_stream(engine, data, 1, b"".join(parts))
+
+
+def test_corrupt_blocks(engine):
+    random.seed(11)
+    base = bz2.compress(corpus.text(60000, seed=9), 1)
+    for t in range(60):
+        b = bytearray(base)
+        for _ in range(random.choice([1, 1, 3])):
+            pos = random.randrange(10, len(b))          # keep the stream header and first magic
+            b[pos] ^= 1 << random.randrange(8)
+        data = bytes(b)
+        units = [u for u in block_units(data, 1)][:1]
+        out, res = engine.decode_batch(data, units, 1 << 20)
+        er, eo = oracle.bzip2_block(data, 8 * units[0].in_off + units[0].in_bit_off, 1, cap=1 << 20)
+        assert res[0].status == er.status, (t, res[0].status, er.status)
+        if er.status == 0:
+            assert out.raw[:res[0].out_len] == eo
+        else:
+            assert res[0].detail == er.detail, (t, res[0].status, res[0].detail, er.detail)
+
+
+def test_truncated_block(engine):
+    base = bz2.compress(corpus.text(30000, seed=4), 1)
+    for cut in (len(base) - 11, len(base) // 2, 40, 12, 9):
+        data = base[:cut]
+        u = _lib.Unit(in_off=4, in_limit=len(data), out_off=_lib.OUT_AUTO, kind=_lib.UNIT_BZIP2_BLOCK, param0=1)
+        _, res = engine.decode_batch(data, [u], 1 << 20)
+        er, _ = oracle.bzip2_block(data, 32, 1, cap=1 << 20)
+        assert res[0].status == er.status == 1, (cut, res[0].status, er.status)
+
+
+def test_out_cap_and_explicit_offsets(engine):
+    d = corpus.text(250000, seed=6)
+    data = bz2.compress(d, 1)
+    n = len(find_magic(data, BLOCK_MAGIC))
+    # explicit spans with slack
+    units = block_units(data, 1, auto=False, caps=[(i * 120000, 110000) for i in range(n)])
+    out, res = engine.decode_batch(data, units, n * 120000)
+    got = b"".join(out.raw[r.out_off:r.out_off + r.out_len] for r in res)
+    assert all(r.status == 0 for r in res) and got == d
+    # capacity too small for the batch: the tail units report SEMZ_E_OUT_CAP
+    units = block_units(data, 1)
+    _, res = engine.decode_batch(data, units, 150000)
+    assert res[0].status == 0 and res[-1].status == 200
