@@ -12,11 +12,14 @@
 
 void orc_xz_next_member_start(const uint8_t *in, size_t in_len, size_t pos,
                               size_t *next, int *status);   /* xz.c */
+void orc_xz_member_ex(const uint8_t *in, size_t in_len, int skip_magic, uint8_t *out, size_t out_cap,
+                      orc_result *res);                     /* xz.c */
 
 void orc_decompress(int fmt, const uint8_t *in, size_t in_len, int all_members,
                     uint32_t opt, uint8_t *out, size_t out_cap, orc_result *res)
 {
     size_t pos = 0, outn = 0;
+    int skip_magic = 0;
     orc_result r;
     memset(res, 0, sizeof *res);
     for (;;) {
@@ -28,7 +31,7 @@ void orc_decompress(int fmt, const uint8_t *in, size_t in_len, int all_members,
         case 2: { orc_gzip_header h; orc_gzip_member(p, n, out + outn, out_cap - outn, &h, &r); break; }
         case 3: orc_bzip2_member(p, n, out + outn, out_cap - outn, &r); break;
         case 6: orc_lzma2(p, n, 0, 0, opt, out + outn, out_cap - outn, &r); break;
-        case 8: orc_xz_member(p, n, out + outn, out_cap - outn, &r); break;
+        case 8: orc_xz_member_ex(p, n, skip_magic, out + outn, out_cap - outn, &r); break;
         default: r.status = SEMZ_E_UNSUPPORTED; r.detail = 0; r.in_end_bit = 0; r.out_len = 0;
         }
         size_t used = (size_t)((r.in_end_bit + 7) >> 3);
@@ -48,6 +51,7 @@ void orc_decompress(int fmt, const uint8_t *in, size_t in_len, int all_members,
             if (st != SEMZ_OK) { res->status = st; res->in_end_bit = 8ull * pos; res->out_len = outn; return; }
             pos = next;
             if (pos == in_len) break;
+            skip_magic = 1;
             continue;
         }
         res->status = SEMZ_E_TRAILING_DATA;
