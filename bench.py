@@ -99,7 +99,6 @@ def main():
     ap.add_argument("--format", default="gzip", choices=["gzip", "zlib"])
     ap.add_argument("--units", type=int, default=0)
     ap.add_argument("--unit-bytes", type=int, default=0)
-    ap.add_argument("--group", type=int, default=0, help="lanes per deflate unit (16/32/64)")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
@@ -130,8 +129,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     eng = _lib.Engine(local)
-    if a.group:
-        eng.set_option("inflate_group", a.group)
     uarr = (_lib.Unit * nunits)(*units)
     d_in = eng.dev_alloc(total_in + 64)
     d_units = eng.dev_alloc(C.sizeof(uarr))
@@ -193,7 +190,6 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "format": a.format, "units_per_gpu": nunits, "unit_bytes": unit_bytes,
                        "compressed_bytes_per_gpu": total_in, "decompressed_bytes_per_gpu": total_out,
-                       "inflate_group": a.group or int(os.environ.get("SEMZ_INFLATE_GROUP", "64")),
                        "sharding": f"units by rank x{world}, no collective", "corpus_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

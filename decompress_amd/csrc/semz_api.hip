@@ -69,8 +69,6 @@ extern "C" int semz_open(int device, semz_ctx **out)
     if (device < 0 || device >= ndev) return -1;
     semz_ctx *c = new semz_ctx();
     c->device = device;
-    c->inflate_group = 64;
-    if (const char *g = getenv("SEMZ_INFLATE_GROUP")) c->inflate_group = atoi(g);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -2; }
     semz_check_tables *h = new semz_check_tables();
     semz_build_check_tables(h);
@@ -99,11 +97,6 @@ extern "C" const char *semz_last_error(const semz_ctx *c) { return c ? c->err : 
 extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
 {
     if (!c || !name) return -1;
-    if (!strcmp(name, "inflate_group")) {
-        if (value != 16 && value != 32 && value != 64) return semz_fail(c, -1, "inflate_group must be 16, 32 or 64");
-        c->inflate_group = (int)value;
-        return 0;
-    }
     if (!strcmp(name, "profile")) { c->profile = value != 0; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
 }
@@ -142,7 +135,7 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
     case SEMZ_UNIT_ZLIB:
     case SEMZ_UNIT_GZIP:
         semz_span_begin(c, "inflate_kernel");
-        semz_launch_inflate(c->inflate_group, (const uint8_t *)d_in, d_units, (uint32_t)nunits, (uint8_t *)d_out,
+        semz_launch_inflate((const uint8_t *)d_in, d_units, (uint32_t)nunits, (uint8_t *)d_out,
                             d_results, (semz_tail *)tails, c->stream);
         semz_span_end(c);
         semz_span_begin(c, "checksum_kernel");

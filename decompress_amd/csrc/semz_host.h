@@ -19,7 +19,6 @@ struct semz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     semz_check_tables *d_tabs = nullptr;
-    int inflate_group = 64;
     std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
     // optional per-kernel timing (semz_set_option "profile"): event pairs on `stream`
     bool profile = false;
@@ -43,7 +42,7 @@ int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p);
 
 extern "C" {
 void semz_build_check_tables(semz_check_tables *t);
-void semz_launch_inflate(int group, const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
+void semz_launch_inflate(const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
                          uint8_t *d_out, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
 void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32_t nunits,
                           semz_result *d_results, const semz_tail *d_tails,

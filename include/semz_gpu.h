@@ -136,8 +136,7 @@ int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
 int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
                              const semz_unit *d_units, size_t nunits,
                              void *d_out, size_t out_cap, semz_result *d_results);
-/* Tunables: "inflate_group" = lanes per deflate unit (16, 32 or 64);
- * "profile" = 1 records a HIP event pair around every kernel of later calls. */
+/* Options: "profile" = 1 records a HIP event pair around every kernel of later calls. */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */
