@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsemz_gpu.so")
+# SEMZ_LIB selects another build of the same library (e.g. the diagnostic libsemz_gpu_stamps.so)
+LIB_PATH = os.environ.get("SEMZ_LIB") or os.path.join(_HERE, "libsemz_gpu.so")
 
 
 class Unit(C.Structure):
