@@ -269,7 +269,7 @@ __device__ __forceinline__ void stage_store(uint8_t *inring, uint4 x, uint64_t v
     }
     *reinterpret_cast<uint4 *>(inring + ((uint32_t)v & (IN_RING - 1))) = x;
 }
-// where staging continues for a reader at wpos: restart at the reader if it jumped (stored blocks, headers)
+// where staging continues for a reader whose next unread bit lies in the dword at wpos: restart at the reader if it jumped (stored blocks, headers)
 __device__ __forceinline__ void stage_rebase(uint64_t wpos, uint64_t &s_hi)
 {
     const uint64_t wfloor = wpos & ~15ull;
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
     const uint64_t amis = (uint64_t)((uintptr_t)in & 15);
     const uint8_t *base16 = in - amis;              // base16 + v is the address of v-offset v
     uint64_t s_hi = 0;                               // input staged up to this v-offset (group-uniform)
+    uint8_t *safe_byte = const_cast<uint8_t *>(base16);  // always-readable address for masked-off gather lanes
     const uint64_t limit_v = un.in_limit + amis;
     BitReader br;
     Status st{SEMZ_OK, 0};
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
     }
     prefix_amount = Gr::bcast(prefix_amount);
     prefix_end = (const uint8_t *)(uintptr_t)Gr::bcast((uint64_t)(uintptr_t)prefix_end);
-    if (alive) stage_blocking(L.inring, base16, limit_v, Gr::bcast(br.wpos), s_hi);
+    if (alive) stage_blocking(L.inring, base16, limit_v, Gr::bcast((br.bitpos() >> 5) << 2), s_hi);
 
     STAMP_DECL
     // ---- main loop: one round per iteration ----
@@ -525,6 +526,70 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
 #define FAIL(c, d) { st.set((c), (d)); ev = EV_DONE; break; }
             // every iteration takes at most eight dwords from the input ring
             while (ev == EV_ROUND && ntok < (uint32_t)QCAP && rbytes < (uint32_t)ROUND_BYTES && br.wpos + 32 <= s_hi) {
+                if (state == ST_HUFF && !br.near_end && dist_mode != MODE_LITONLY) {
+                    // ---- fast path: tokens that need no end-of-input accounting, no long codes and no
+                    // block events.  The bit window is two dwords of the input ring read with
+                    // v_alignbit; anything unusual leaves the loop before the token is committed and
+                    // is decoded again by the general code below.
+                    const uint64_t bits0 = br.bitpos();
+                    const uint64_t wlo0 = (bits0 >> 5) << 2;                   // v-offset of the dword holding the next bit
+                    const uint64_t e_end = s_hi < (limit_v & ~3ull) ? s_hi : (limit_v & ~3ull);
+                    const uint32_t end32 = (uint32_t)e_end, wp0 = (uint32_t)wlo0;
+                    uint32_t wp = wp0, bo = (uint32_t)bits0 & 31;
+                    if (e_end >= wlo0 + 16) {
+                        uint32_t lo = *reinterpret_cast<const uint32_t *>(L.inring + (wp & (IN_RING - 1)));
+                        uint32_t hi = *reinterpret_cast<const uint32_t *>(L.inring + ((wp + 4) & (IN_RING - 1)));
+                        const uint32_t rb_lim = room >= 258u + ROUND_BYTES ? (uint32_t)ROUND_BYTES : (room >= 258u ? (room - 258u < (uint32_t)ROUND_BYTES ? room - 258u : (uint32_t)ROUND_BYTES) : 0u);
+                        while ((int32_t)(end32 - wp) >= 16 && rbytes < rb_lim && ntok < (uint32_t)QCAP) {
+                            if (bo >= 32) {
+                                lo = hi;
+                                hi = *reinterpret_cast<const uint32_t *>(L.inring + ((wp + 8) & (IN_RING - 1)));
+                                wp += 4;
+                                bo -= 32;
+                            }
+                            const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, bo);
+                            const uint32_t e = L.lit_root[x & ((1u << LIT_ROOT_BITS) - 1)];
+                            const uint32_t cl = e & 15;
+                            if (cl == 0) break;
+                            if (e & LIT_FLAG) {
+                                L.ring[(rpos + rbytes) & RING_MASK] = (uint8_t)(e >> 8);
+                                rbytes++;
+                                bo += cl;
+                                continue;
+                            }
+                            const uint32_t lx = (e >> 5) & 7;
+                            if (lx == 7) break;
+                            const uint32_t length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(x, cl, lx);
+                            uint32_t bo2 = bo + cl + lx, lo2 = lo, hi2 = hi, wp2 = wp;
+                            if (bo2 >= 32) {
+                                lo2 = hi;
+                                hi2 = *reinterpret_cast<const uint32_t *>(L.inring + ((wp + 8) & (IN_RING - 1)));
+                                wp2 += 4;
+                                bo2 -= 32;
+                            }
+                            const uint32_t y = __builtin_amdgcn_alignbit(hi2, lo2, bo2);
+                            const uint32_t d = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
+                            const uint32_t dl = d & 15;
+                            if (dl == 0 || (d & DIST_BAD)) break;
+                            const uint32_t dx = (d >> 4) & 15;
+                            const uint32_t distance = 1 + (((d >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
+                            const uint32_t have = avail + rbytes;
+                            if (distance > (have < wsize ? have : wsize)) break;
+                            lo = lo2; hi = hi2; wp = wp2;
+                            bo = bo2 + dl + dx;
+                            L.queue[ntok] = make_uint2(T_MATCH | (length << 2) | (rbytes << 16), distance);
+                            ntok++;
+                            rbytes += length;
+                        }
+                        // hand the position back to the general reader
+                        const uint64_t bits1 = 8 * (wlo0 + (uint64_t)(wp - wp0)) + bo;
+                        br.wpos = (bits1 >> 5) << 2;
+                        br.skip = (int)(bits1 & 31);
+                        br.buf = 0;
+                        br.cnt = 0;
+                        if (!(ntok < (uint32_t)QCAP && rbytes < (uint32_t)ROUND_BYTES && br.wpos + 32 <= s_hi)) break;
+                    }
+                }
                 br.refill();
                 if (state == ST_HUFF) {
                     if (!br.near_end) huff_step(bool_false{});
@@ -606,7 +671,7 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
         COUNT(0, leader ? ntok : 0); COUNT(1, 1);
 
         // ---- top up the input ring: the loads are issued here and stored after the resolve ----
-        const uint64_t wp = Gr::bcast(br.wpos);
+        const uint64_t wp = Gr::bcast((br.bitpos() >> 5) << 2);
         stage_rebase(wp, s_hi);
         const uint32_t nst = (uint32_t)(((wp & ~15ull) + IN_RING - s_hi) / STAGE_BYTES);
         const uint64_t sv0 = s_hi + 16u * gl, sv1 = sv0 + STAGE_BYTES;
@@ -634,26 +699,44 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
             // far matches: no byte of the source was produced in this round, so the gathers of four
             // tokens (32 bytes each) are put in flight together
             while (farm) {
-                uint32_t fl[4], fp[4], fv[4], fw[4];
+                uint32_t fl[4], fp[4], gv[4][2], lv[4][2];
                 int64_t fs[4];
+                bool neg = false;
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
-                    fl[b] = 0; fp[b] = 0; fs[b] = 0; fv[b] = 0; fw[b] = 0;
-                    if (farm) {
-                        const int j = __builtin_ctz(farm);
-                        farm &= farm - 1;
-                        const uint2 tk = L.queue[j];
-                        fl[b] = (tk.x >> 2) & 0x3FFF;
-                        fp[b] = tk.x >> 16;
-                        fs[b] = (int64_t)(pos0 + fp[b]) - (int64_t)tk.y;
-                        if ((uint32_t)gl < fl[b]) fv[b] = history_byte(fs[b] + gl, near_lo, L.ring, shift, ob, prefix_end);
-                        if ((uint32_t)gl + G < fl[b]) fw[b] = history_byte(fs[b] + gl + G, near_lo, L.ring, shift, ob, prefix_end);
-                    }
+                    const uint32_t more = farm;
+                    const uint2 tk = L.queue[more ? __builtin_ctz(more) : 0];
+                    farm &= farm - 1;
+                    fl[b] = more ? (tk.x >> 2) & 0x3FFF : 0;
+                    fp[b] = tk.x >> 16;
+                    fs[b] = (int64_t)(pos0 + fp[b]) - (int64_t)tk.y;
                 }
+                // unconditional loads (HBM through L2: the bytes were written by this wave; LDS ring), selected below
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    if ((uint32_t)gl < fl[b]) L.ring[(uint32_t)(pos0 + fp[b] + gl + shift) & RING_MASK] = (uint8_t)fv[b];
-                    if ((uint32_t)gl + G < fl[b]) L.ring[(uint32_t)(pos0 + fp[b] + gl + G + shift) & RING_MASK] = (uint8_t)fw[b];
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int64_t s = fs[b] + gl + G * h;
+                        const bool act = (uint32_t)gl + G * h < fl[b];
+                        const bool useg = act && s >= 0 && s < near_lo;
+                        gv[b][h] = __hip_atomic_load(useg ? ob + s : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lv[b][h] = L.ring[(uint32_t)((uint64_t)s + shift) & RING_MASK];
+                        neg = neg || (act && s < 0);
+                    }
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int64_t s = fs[b] + gl + G * h;
+                        if ((uint32_t)gl + G * h < fl[b] && s >= 0)
+                            L.ring[(uint32_t)(pos0 + fp[b] + gl + G * h + shift) & RING_MASK] =
+                                (uint8_t)(s >= near_lo ? lv[b][h] : gv[b][h]);
+                    }
+                if (__any(neg)) {                      // preset dictionary bytes (zlib FDICT, deflate prefix)
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        for (uint32_t k = gl; k < fl[b] && k < 2 * G; k += G)
+                            if (fs[b] + k < 0) L.ring[(uint32_t)(pos0 + fp[b] + k + shift) & RING_MASK] = prefix_end[fs[b] + k];
                 }
 #pragma unroll
                 for (int b = 0; b < 4; b++)
@@ -745,7 +828,7 @@ __global__ __launch_bounds__(64, 1) void inflate_kernel(const uint8_t *in, const
                 build_tree<CLEN_ROOT_BITS>(L.clens, 19, L.clen, L.clen_sorted, L.clen_root, clen_entry);
                 const int tstatus = (int)L.clen.status;
                 // the code lengths take at most 320 * 14 bits: make sure they are staged
-                stage_blocking(L.inring, base16, limit_v, Gr::bcast(br.wpos), s_hi);
+                stage_blocking(L.inring, base16, limit_v, Gr::bcast((br.bitpos() >> 5) << 2), s_hi);
                 if (leader) {
                     overread = (final_block ? 0 : MIN_BLOCK_BITS) + trailing_bits;    // deflate.lisp:392-396
                     if (tstatus == SEMZ_OK) {
