@@ -19,7 +19,7 @@ class Unit(C.Structure):
         ("kind", C.c_uint32), ("flags", C.c_uint32),
         ("in_bit_off", C.c_uint32), ("param0", C.c_uint32),
         ("param1", C.c_uint32), ("param2", C.c_uint32),
-        ("param3", C.c_uint32), ("reserved", C.c_uint32),
+        ("param3", C.c_uint32), ("filters", C.c_uint32),
         ("prefix_off", C.c_uint64), ("prefix_len", C.c_uint64),
         ("size_in", C.c_uint64), ("size_out", C.c_uint64),
     ]
@@ -43,7 +43,9 @@ class StreamInfo(C.Structure):
 # unit kinds / formats / flags (semz_gpu.h)
 UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2 = range(6)
 FMT_DEFLATE, FMT_ZLIB, FMT_GZIP, FMT_BZIP2, FMT_RAW_LZMA, FMT_LZMA, FMT_RAW_LZMA2, FMT_LZMA2, FMT_XZ = range(9)
-UF_HAVE_DICT_FN, UF_BCJ_X86, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE, UF_DELTA = 1, 2, 4, 8, 16
+UF_HAVE_DICT_FN, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE = 1, 4, 8
+FILTER_DELTA, FILTER_X86 = 1, 2
+CHECK_NONE, CHECK_CRC32, CHECK_CRC64, CHECK_SHA256 = 0, 1, 4, 10
 
 OUT_AUTO = 0xFFFFFFFFFFFFFFFF
 

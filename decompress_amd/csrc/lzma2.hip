@@ -1,2 +1,632 @@
+// lzma2.hip -- gfx950 kernels for xz blocks and raw LZMA2 streams.
+//
+// Replaces, per unit, the reference loops
+//   lzma-range-decoder, lrd-*            lzma.lisp:49-198
+//   decode-lzma-length / -distance       lzma.lisp:247-341
+//   decode-lzma (eof-mode :never)        lzma.lisp:566-775
+//   LZMA2 control-byte state machine     lzma2.lisp:77-204
+//   xz block end (sizes, padding, check) xz.lisp:426-457
+//   x86 BCJ filter                       xz-bcj-filters.lisp:169-219
+//   delta filter                         xz.lisp:238-258
+//
+// lzma2_kernel: one unit per 64-lane wavefront (one wavefront per workgroup).
+// LZMA is bit-serial with adaptive probabilities, so the symbol loop is
+// wave-uniform: range/code, the rep distances and every branch live in scalar
+// registers, the 11-bit probabilities (up to 14,135 of them, 28 KiB) live in
+// LDS and come back through v_readfirstlane; the compressed input is read with
+// scalar dword loads.  All 64 lanes take part in match copies, stored chunks
+// and flushes.  Output is staged in an 8 KiB LDS ring (index == HBM address mod
+// 16) that serves as the near dictionary; older history is read back from HBM
+// through L2.  The block's own output span is the dictionary: every xz block
+// starts with a dictionary reset (lzma2.lisp:97-98).
+//
+// bcj_x86_kernel / delta_kernel: the block's filter chain, applied in place in
+// HBM after LZMA2, then checksums.hip computes and compares the block check.
 #include "semz_host.h"
-int semz_run_lzma2(semz_ctx *c, const uint8_t *, size_t, const semz_unit *, uint32_t, uint8_t *, size_t, semz_result *, semz_tail *) { return semz_fail(c, -4, "lzma2 not built yet"); }
+
+namespace {
+
+constexpr int LZ_RING = 8192;
+constexpr int LZ_MASK = LZ_RING - 1;
+constexpr int LZ_FLUSH = 1024;                 // 64 lanes x 16 bytes
+constexpr int MAX_MATCH = 273;                 // +lzma-max-expansion-length+, lzma.lisp:233-238
+
+// probability layout (uint16 indices), lzma.lisp:220-231, 295-313, 428-460
+enum {
+    P_IS_LIT = 0, P_IS_SIMPLE = 192, P_USES_REP0 = 204, P_IS_SHORT = 216, P_IS_REP1 = 408, P_IS_REP2 = 420,
+    P_LEN_SIMPLE = 432, P_LEN_REP = 946, P_SLOT = 1460, P_MID = 1716, P_ALIGN = 1831, P_LIT = 1847,
+    P_TOTAL = 1847 + (0x300 << 4) + 1
+};
+enum { LEN_CHOICE = 0, LEN_LOW = 2, LEN_MID = 130, LEN_HIGH = 258 };
+
+typedef const __attribute__((address_space(4))) uint32_t *k_u32p;   // scalar-load view of read-only memory
+
+template <typename T> __device__ __forceinline__ T uni(T v)
+{
+    if constexpr (sizeof(T) == 8) {
+        uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else {
+        return (T)__builtin_amdgcn_readfirstlane((int)v);
+    }
+}
+
+struct __align__(16) LzLds {
+    uint8_t ring[LZ_RING];
+    uint16_t probs[P_TOTAL];
+};
+
+// Wave-uniform decoder state.  Reads go through next_byte(); after the first
+// failure every later read returns 0 and the symbol loops run on until they
+// poll `status`, which keeps the first failure (the one the reference raises).
+struct Lz {
+    // byte source with nested limits (io.lisp:258-323): v-offsets = offset inside `in` + (in & 3)
+    k_u32p base4;
+    uint64_t pos;         // next byte
+    uint64_t phys_end;    // physical end of the input           -> SEMZ_EOF
+    uint64_t block_end;   // declared xz compressed size, or ~0  -> SEMZ_E_XZ_BLOCK_OVERRUN
+    uint64_t chunk_end;   // LZMA2 chunk compressed size, or ~0  -> SEMZ_E_LZMA2_CHUNK_OVERRUN
+    uint64_t rd_end;      // min of the three
+    uint64_t apos;        // v-offset of the dword cur was taken from (multiple of 4)
+    uint32_t cur;         // unread bytes of that dword
+    int32_t status;
+    uint32_t detail;
+    // range decoder
+    uint32_t range, code;
+
+    __device__ __forceinline__ void fail(int st, uint32_t d) { if (status == SEMZ_OK) { status = st; detail = d; } }
+    // cur holds the unread bytes of the dword at apos, already shifted down.  The dword index is kept in
+    // its own variable: were the load address derived from `pos`, the compiler folds "pos is a multiple of
+    // four here" into an s_load from a misaligned base plus a byte offset, and the scalar memory unit drops
+    // the low two bits of the base.
+    __device__ __forceinline__ void load_cur()
+    {
+        apos = pos & ~3ull;
+        cur = 0;
+        if (apos < phys_end) cur = base4[apos >> 2] >> (8 * ((uint32_t)pos & 3));
+    }
+    __device__ __forceinline__ void set_limits()
+    {
+        rd_end = phys_end < block_end ? phys_end : block_end;
+        if (chunk_end < rd_end) rd_end = chunk_end;
+    }
+    __device__ __forceinline__ uint32_t next_byte()
+    {
+        if (pos >= rd_end) {
+            // innermost limit that has been reached wins; otherwise the input itself ended
+            fail(pos >= chunk_end ? SEMZ_E_LZMA2_CHUNK_OVERRUN : pos >= block_end ? SEMZ_E_XZ_BLOCK_OVERRUN : SEMZ_EOF, 0);
+            return 0;
+        }
+        const uint32_t b = cur & 0xFF;
+        cur >>= 8;
+        pos++;
+        if (((uint32_t)pos & 3) == 0) {
+            apos += 4;
+            if (apos < phys_end) cur = base4[apos >> 2];
+        }
+        return b;
+    }
+    __device__ __forceinline__ void normalize()                          // lzma.lisp:64-73
+    {
+        if (range < (1u << 24)) {
+            range <<= 8;
+            code = (code << 8) | next_byte();
+            if (!(code < range)) fail(SEMZ_E_LZMA_CODE_RANGE, 0);
+        }
+    }
+    __device__ __forceinline__ uint32_t bit(uint16_t *probs, uint32_t idx)   // lzma.lisp:83-116
+    {
+        const uint32_t p = uni((uint32_t)probs[idx]);
+        const uint32_t bound = p * (range >> 11);
+        uint32_t b, np;
+        if (code >= bound) { range -= bound; code -= bound; np = p - (p >> 5); b = 1; }
+        else { range = bound; np = p + ((2048 - p) >> 5); b = 0; }
+        if ((threadIdx.x & 63) == 0) probs[idx] = (uint16_t)np;
+        normalize();
+        return b;
+    }
+    __device__ __forceinline__ uint32_t be_bits(uint16_t *probs, uint32_t base, uint32_t count)   // lzma.lisp:122-135
+    {
+        const uint32_t bound = 1u << count;
+        uint32_t m = 1;
+        while (m < bound) m = (m << 1) | bit(probs, base + m);
+        return m - bound;
+    }
+    __device__ __forceinline__ uint32_t le_bits(uint16_t *probs, uint32_t base, uint32_t count)   // lzma.lisp:138-145
+    {
+        return __brev(be_bits(probs, base, count)) >> (32 - count);
+    }
+    __device__ __forceinline__ uint32_t fixed_bits(uint32_t count)                            // lzma.lisp:174-192
+    {
+        uint32_t res = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            const uint32_t bound = range >> 1;
+            range = bound;
+            if (code >= bound) {
+                code -= bound;
+                if (code == bound) fail(SEMZ_E_LZMA_CODE_RANGE, 0);
+                res = (res << 1) | 1;
+            } else res <<= 1;
+            normalize();
+        }
+        return res;
+    }
+    __device__ __forceinline__ uint32_t length(uint16_t *probs, uint32_t dec, uint32_t pos_state)   // lzma.lisp:247-257
+    {
+        if (bit(probs, dec + LEN_CHOICE) == 0) return be_bits(probs, dec + LEN_LOW + 8 * pos_state, 3);
+        if (bit(probs, dec + LEN_CHOICE + 1) == 0) return 8 + be_bits(probs, dec + LEN_MID + 8 * pos_state, 3);
+        return 16 + be_bits(probs, dec + LEN_HIGH, 8);
+    }
+    __device__ __forceinline__ uint32_t distance(uint16_t *probs, uint32_t raw_len)            // lzma.lisp:323-341
+    {
+        const uint32_t slot = be_bits(probs, P_SLOT + 64 * (raw_len < 3 ? raw_len : 3), 6);
+        if (slot < 4) return slot;
+        const uint32_t bit_count = (slot >> 1) - 1;
+        const uint32_t min_dist = (2u | (slot & 1)) << bit_count;
+        if (slot < 14) return min_dist + le_bits(probs, P_MID + min_dist - slot, bit_count);
+        const uint32_t hi = fixed_bits(bit_count - 4) << 4;
+        return min_dist + hi + le_bits(probs, P_ALIGN, 4);
+    }
+};
+
+__device__ __forceinline__ uint32_t ld_bytes_le(const uint8_t *p, int n)
+{
+    uint32_t v = 0;
+    for (int i = 0; i < n; i++) v |= (uint32_t)p[i] << (8 * i);
+    return v;
+}
+
+__global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
+                                                      uint8_t *out, semz_result *results, semz_tail *tails)
+{
+    __shared__ LzLds L;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    semz_unit un;
+    {
+        k_u32p up = (k_u32p)(uintptr_t)(units + u);
+        uint32_t w[sizeof(semz_unit) / 4];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(semz_unit) / 4); i++) w[i] = up[i];
+        __builtin_memcpy(&un, w, sizeof un);
+    }
+    uint8_t *ob = out + un.out_off;
+    const uint32_t shift = (uint32_t)((uintptr_t)ob & 15);
+    const uint64_t out_cap = un.out_cap;
+    const uint32_t dict_size = un.param0;
+    const bool is_xz = un.kind == SEMZ_UNIT_XZ_BLOCK;
+    uint8_t *safe_byte = out;                          // always-readable address for masked-off gather lanes
+
+    const uint64_t amis = (uint64_t)((uintptr_t)in & 3);
+    Lz z;
+    z.base4 = (k_u32p)((uintptr_t)in - amis);
+    z.pos = un.in_off + amis;
+    z.phys_end = un.in_limit + amis;
+    z.block_end = (is_xz && (un.flags & SEMZ_UF_HAVE_IN_SIZE)) ? z.pos + un.size_in : ~0ull;
+    if (z.block_end < z.pos) z.block_end = ~0ull;      // size_in near 2^64: cannot be reached
+    z.chunk_end = ~0ull;
+    z.set_limits();
+    z.status = SEMZ_OK;
+    z.detail = 0;
+    z.range = 0; z.code = 0;
+    z.load_cur();
+    const uint64_t data_start = z.pos;
+
+    // LZMA state variables (lzma-state-vars, lzma.lisp:428-460)
+    uint32_t rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, history = 0, total_i = 0;
+    uint32_t lc = 0, lp_mask = 0, pb_mask = 0;
+    bool have_state = false;
+    enum { NEED_DICT = 0, NEED_PROPS = 1, NEED_NONE = 2 };
+    int need = NEED_DICT;
+
+    uint64_t p = 0;            // output position
+    uint64_t dict_base = 0;    // position of the last dictionary reset
+    uint64_t flushed = 0;
+
+    // moves whole 1 KiB pieces of the ring to HBM; `all` also moves the tail
+    auto flush = [&](bool all) {
+        const uint32_t head = (16 - shift) & 15;
+        if (flushed == 0 && head && (p >= head || all)) {
+            const uint32_t n = p < head ? (uint32_t)p : head;
+            if (lane < n) ob[lane] = L.ring[(lane + shift) & LZ_MASK];
+            flushed = n;
+        }
+        if (flushed || !head) {
+            while (p - flushed >= (uint64_t)LZ_FLUSH) {
+                const uint64_t a = flushed + 16u * lane;
+                const uint4 v = *reinterpret_cast<const uint4 *>(&L.ring[(uint32_t)(a + shift) & LZ_MASK]);
+                *reinterpret_cast<uint4 *>(ob + a) = v;
+                flushed += LZ_FLUSH;
+            }
+            if (all) {
+                const uint32_t pieces = (uint32_t)((p - flushed) >> 4);
+                if (lane < pieces) {
+                    const uint64_t a = flushed + 16u * lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&L.ring[(uint32_t)(a + shift) & LZ_MASK]);
+                    *reinterpret_cast<uint4 *>(ob + a) = v;
+                }
+                flushed += 16ull * pieces;
+                const uint32_t rest = (uint32_t)(p - flushed);
+                if (lane < rest) ob[flushed + lane] = L.ring[(uint32_t)(flushed + lane + shift) & LZ_MASK];
+                flushed = p;
+            }
+        }
+    };
+    // byte of history at position s < p: the ring holds [p - (LZ_RING - MAX_MATCH - LZ_FLUSH) .. p) at least
+    auto history_byte = [&](uint64_t s) -> uint32_t {
+        if (s + (LZ_RING - MAX_MATCH) > p) return uni((uint32_t)L.ring[(uint32_t)(s + shift) & LZ_MASK]);
+        return uni((uint32_t)__hip_atomic_load(ob + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+
+    // ---- LZMA2 control loop (lzma2.lisp:77-204) ----
+    for (;;) {
+        if (z.status != SEMZ_OK) break;
+        const uint32_t control = z.next_byte();
+        if (z.status != SEMZ_OK) break;
+        if (control >= 0x80) {
+            uint32_t b0 = z.next_byte(), b1 = z.next_byte(), b2 = z.next_byte(), b3 = z.next_byte();
+            if (z.status != SEMZ_OK) break;
+            const uint64_t usize = (((uint64_t)(control & 31) << 16) | (b0 << 8) | b1) + 1;
+            const uint64_t csize = ((b2 << 8) | b3) + 1;
+            if (need == NEED_DICT && control < 0xE0) { z.fail(SEMZ_E_LZMA2_NEED_DICT_RESET, 0); break; }
+            if (need == NEED_PROPS && control < 0xC0) { z.fail(SEMZ_E_LZMA2_NEED_PROPS, 0); break; }
+            need = NEED_NONE;
+            if (control >= 0xC0) {
+                const uint32_t octet = z.next_byte();               // parse-lzma2-props, lzma2.lisp:31-38
+                if (z.status != SEMZ_OK) break;
+                const uint32_t nlc = octet % 9, nlp = (octet / 9) % 5, npb = octet / 45;
+                if (npb > 4) { z.fail(SEMZ_E_LZMA_PB, npb); break; }
+                if (nlc + nlp > 4) { z.fail(SEMZ_E_LZMA2_LCLP, nlc + nlp); break; }
+                lc = nlc; lp_mask = (1u << nlp) - 1; pb_mask = (1u << npb) - 1;
+            } else if (!have_state) { z.fail(SEMZ_E_LZMA2_NO_STATE, 0); break; }
+            if (control >= 0xE0) dict_base = p;
+            if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
+            // counted source for the chunk (lzma2.lisp:111-116), then the range decoder (lzma.lisp:55-62)
+            z.chunk_end = z.pos + csize;
+            z.set_limits();
+            if (z.next_byte() != 0) z.fail(SEMZ_E_LZMA_FIRST_BYTE, 0);
+            z.range = 0xFFFFFFFFu;
+            z.code = 0;
+            for (int i = 0; i < 4; i++) z.code = (z.code << 8) | z.next_byte();
+            if (z.status == SEMZ_OK && !(z.code < z.range)) z.fail(SEMZ_E_LZMA_CODE_START, 0);
+            if (z.status != SEMZ_OK) break;
+            if (control >= 0xA0 || !have_state) {                   // fresh lzma-state-vars (lzma2.lisp:144-145)
+                for (uint32_t i = lane; i < (uint32_t)P_TOTAL; i += 64) L.probs[i] = 1024;
+                rep0 = rep1 = rep2 = rep3 = 0; history = 0; total_i = 0;
+                lds_sync();
+            }
+            have_state = true;
+
+            // ---- decode-lzma, eof-mode :never (lzma.lisp:566-775) ----
+            const uint64_t end = p + usize;
+            for (;;) {
+                if (z.status != SEMZ_OK) break;
+                const uint32_t pos_state = total_i & pb_mask;
+                if (p == end) {
+                    if (z.code != 0) {                               // handle-eof-insanity, lzma.lisp:644-647
+                        bool marker = false;                         // probe-eof, lzma.lisp:623-638
+                        if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 1 &&
+                            z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
+                            const uint32_t len = z.length(L.probs, P_LEN_SIMPLE, pos_state);
+                            marker = z.distance(L.probs, len) == 0xFFFFFFFFu;
+                        }
+                        z.fail(marker ? SEMZ_E_LZMA_ILLEGAL_EOF : SEMZ_E_LZMA_CONTINUES, 0);
+                    }
+                    break;
+                }
+                uint32_t len;
+                if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 0) {
+                    // decode-literal, lzma.lisp:661-688
+                    const uint32_t prev = p == dict_base ? 0u : uni((uint32_t)L.ring[(uint32_t)(p - 1 + shift) & LZ_MASK]);
+                    const uint32_t base = P_LIT + 0x300u * (((total_i & lp_mask) << lc) | (prev >> (8 - lc)));
+                    uint32_t symbol = 1;
+                    if (history >= 7) {
+                        // decode-lzma-literal/match-case, lzma.lisp:497-518
+                        if (p - dict_base < (uint64_t)rep0 + 1) { z.fail(SEMZ_E_UNSUPPORTED, 1); break; }
+                        const uint32_t match_byte = history_byte(p - 1 - rep0);
+                        for (int bit_i = 7; bit_i >= 0; bit_i--) {
+                            const uint32_t mb = (match_byte >> bit_i) & 1;
+                            const uint32_t b = z.bit(L.probs, base + 0x100 + (mb << 8) + symbol);
+                            symbol = (symbol << 1) | b;
+                            if (mb != b) break;
+                        }
+                    }
+                    while (symbol < 0x100) symbol = (symbol << 1) | z.bit(L.probs, base + symbol);
+                    if (lane == 0) L.ring[(uint32_t)(p + shift) & LZ_MASK] = (uint8_t)symbol;
+                    p++;
+                    total_i++;
+                    history = history < 4 ? 0 : history < 10 ? history - 3 : history - 6;   // lzma.lisp:615
+                    if (p - flushed >= (uint64_t)LZ_FLUSH + 16) { lds_sync(); flush(false); }
+                    continue;
+                }
+                if (z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
+                    const uint32_t rl = z.length(L.probs, P_LEN_SIMPLE, pos_state);
+                    history = history < 7 ? 7 : 10;
+                    rep3 = rep2; rep2 = rep1; rep1 = rep0;
+                    rep0 = z.distance(L.probs, rl);
+                    if (rep0 == 0xFFFFFFFFu) { z.fail(SEMZ_E_LZMA_ILLEGAL_EOF, 0); break; }   // lzma.lisp:727-730
+                    len = rl + 2;
+                } else if (z.bit(L.probs, P_USES_REP0 + history) == 0) {
+                    if (z.bit(L.probs, P_IS_SHORT + (history << 4) + pos_state) == 0) {
+                        history = history < 7 ? 9 : 11;
+                        len = 1;
+                    } else {
+                        history = history < 7 ? 8 : 11;
+                        len = 2 + z.length(L.probs, P_LEN_REP, pos_state);
+                    }
+                } else {
+                    uint32_t t;
+                    if (z.bit(L.probs, P_IS_REP1 + history) == 0) { t = rep1; rep1 = rep0; rep0 = t; }
+                    else if (z.bit(L.probs, P_IS_REP2 + history) == 0) { t = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                    else { t = rep3; rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                    history = history < 7 ? 8 : 11;
+                    len = 2 + z.length(L.probs, P_LEN_REP, pos_state);
+                }
+                if (z.status != SEMZ_OK) break;
+                // handle-match, lzma.lisp:600-612
+                const uint64_t dist = (uint64_t)rep0 + 1;
+                if (!(dist <= dict_size)) { z.fail(SEMZ_E_LZMA_DICT_SIZE, 0); break; }
+                if (!(dist <= p - dict_base)) { z.fail(SEMZ_E_LZMA_NO_DATA, 0); break; }
+                if (!(p + len <= end)) { z.fail(SEMZ_E_LZMA_MATCH_SIZE, 0); break; }
+                {
+                    // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
+                    lds_sync();
+                    const uint64_t src = p - dist;
+                    const bool all_near = src + (LZ_RING - MAX_MATCH) > p + len;
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        const uint64_t s = src + (dist >= len ? k : k % (uint32_t)dist);
+                        uint32_t b;
+                        if (all_near) b = L.ring[(uint32_t)(s + shift) & LZ_MASK];
+                        else {
+                            const bool useg = k < len && s + (LZ_RING - MAX_MATCH) <= p;
+                            const uint32_t gv = __hip_atomic_load(useg ? ob + s : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint32_t lv = L.ring[(uint32_t)(s + shift) & LZ_MASK];
+                            b = useg ? gv : lv;
+                        }
+                        if (k < len) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = (uint8_t)b;
+                    }
+                    lds_sync();
+                }
+                p += len;
+                total_i += len;
+                if (p - flushed >= (uint64_t)LZ_FLUSH + 16) flush(false);
+            }
+            total_i &= 15;
+            if (z.status != SEMZ_OK) break;
+            if (z.pos != z.chunk_end) { z.fail(SEMZ_E_LZMA2_CHUNK_SHORT, 0); break; }   // lzma2.lisp:200-201
+            z.chunk_end = ~0ull;
+            z.set_limits();
+        } else if (control > 2) {
+            z.fail(SEMZ_E_LZMA2_CONTROL, control);
+            break;
+        } else if (control >= 1) {
+            // stored chunk (lzma2.lisp:152-189)
+            const uint32_t b0 = z.next_byte(), b1 = z.next_byte();
+            if (z.status != SEMZ_OK) break;
+            const uint64_t usize = ((b0 << 8) | b1) + 1;
+            if (control == 2) {
+                if (need == NEED_DICT) { z.fail(SEMZ_E_LZMA2_NEED_DICT_RESET, 0); break; }
+                need = NEED_NONE;
+            } else {
+                need = NEED_PROPS;
+                dict_base = p;
+            }
+            if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
+            if (z.pos + usize > z.rd_end) {                          // bs-read-sequence with eof-error-p
+                z.pos = z.rd_end;
+                (void)z.next_byte();
+                break;
+            }
+            const uint8_t *src = in + (z.pos - amis);
+            lds_sync();
+            for (uint64_t off = 0; off < usize; off += LZ_FLUSH) {
+                const uint32_t n = usize - off < (uint64_t)LZ_FLUSH ? (uint32_t)(usize - off) : (uint32_t)LZ_FLUSH;
+                for (uint32_t k = lane; k < n; k += 64) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = src[off + k];
+                p += n;
+                lds_sync();
+                flush(false);
+            }
+            z.pos += usize;
+            z.load_cur();
+            if (have_state) total_i = (total_i + (uint32_t)usize) & 15;   // lzma2.lisp:184-188
+        } else {
+            break;                                                   // end of the LZMA2 stream
+        }
+    }
+    lds_sync();
+    flush(true);
+
+    // ---- xz block end (xz.lisp:426-457) and results ----
+    semz_tail t{};
+    semz_result r{};
+    const uint64_t real_csize = z.pos - data_start;
+    if (is_xz && z.status == SEMZ_OK) {
+        if ((un.flags & SEMZ_UF_HAVE_IN_SIZE) && real_csize != un.size_in) z.fail(SEMZ_E_XZ_BLOCK_SHORT, 0);
+        else if ((un.flags & SEMZ_UF_HAVE_OUT_SIZE) && p != un.size_out) z.fail(SEMZ_E_XZ_BLOCK_OUT_SIZE, 0);
+        else {
+            z.block_end = ~0ull;
+            z.set_limits();
+            z.load_cur();
+            const uint32_t pad = (4 - ((uint32_t)real_csize & 3)) & 3;
+            for (uint32_t k = 0; k < pad && z.status == SEMZ_OK; k++)
+                if (z.next_byte() != 0) z.fail(SEMZ_E_XZ_BLOCK_PADDING, 0);
+            if (z.status == SEMZ_OK) {
+                const uint32_t ctype = un.param1;
+                const uint32_t cs = ctype == SEMZ_CHECK_CRC32 ? 4 : ctype == SEMZ_CHECK_CRC64 ? 8 : ctype == SEMZ_CHECK_SHA256 ? 32 : 0;
+                t.check_kind = ctype == SEMZ_CHECK_CRC32 ? SEMZ_TK_CRC32 : ctype == SEMZ_CHECK_CRC64 ? SEMZ_TK_CRC64
+                               : ctype == SEMZ_CHECK_SHA256 ? SEMZ_TK_SHA256 : SEMZ_TK_NONE;
+                if (z.pos + cs <= z.phys_end) {
+                    t.have_check = 1;
+                    const uint8_t *cp = in + (z.pos - amis);
+                    for (uint32_t k = 0; k < cs / 4; k++) t.want[k] = ld_bytes_le(cp + 4 * k, 4);
+                    z.pos += cs;
+                } else {
+                    z.pos = z.phys_end;                              // bs-read-le runs into the end: eof
+                }
+            }
+        }
+    }
+    t.trailer_end_bit = 8 * (z.pos - amis);
+    r.status = z.status;
+    r.detail = z.status == SEMZ_OK ? (uint32_t)(real_csize >> 32) : z.detail;
+    r.aux = (uint32_t)real_csize;
+    r.in_end_bit = 8 * (z.pos - amis);
+    r.out_len = p;
+    r.out_off = un.out_off;
+    if (lane == 0) {
+        results[u] = r;
+        tails[u] = t;
+    }
+}
+
+// ---- x86 BCJ inverse in place (xz-bcj-filters.lisp:169-219), one wave per unit ----
+// The filter state changes only at E8/E9 bytes.  The block is walked in 1 KiB
+// pieces staged in LDS: all lanes mark the candidate bytes of the piece, then
+// the wave-uniform state machine visits the candidates in order and patches
+// the operands in LDS; the piece is written back with 16-byte stores.  A
+// 4-byte overlap carries operands that straddle pieces.
+constexpr int BCJ_PIECE = 1024;
+
+__global__ __launch_bounds__(64) void bcj_x86_kernel(const semz_unit *units, uint32_t nunits, uint8_t *out,
+                                                     const semz_result *results, int stage)
+{
+    __shared__ __align__(16) uint8_t buf[BCJ_PIECE + 16];
+    __shared__ uint32_t cand[BCJ_PIECE / 32];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const semz_unit un = units[u];
+    const semz_result r = results[u];
+    if (r.status != SEMZ_OK || ((un.filters >> (4 * stage)) & 15) != SEMZ_FILTER_X86) return;
+    uint8_t *ob = out + r.out_off;
+    const uint64_t n = r.out_len;
+    if (n < 5) return;
+    const uint64_t limit = n - 5;                      // candidates at i <= limit are processed
+    const uint32_t now_pos0 = un.param2;
+    uint32_t prev_mask = 0, prev_pos = 0u - 5u;
+    if ((uint32_t)(now_pos0 - prev_pos) > 5) prev_pos = now_pos0 - 5;
+    uint64_t next_i = 0;                               // first byte not yet consumed by the state machine
+    for (uint64_t base = 0; base <= limit; base += BCJ_PIECE) {
+        // stage [base, base + BCJ_PIECE + 4)
+        const uint64_t span = n - base < (uint64_t)(BCJ_PIECE + 4) ? n - base : (uint64_t)(BCJ_PIECE + 4);
+        for (uint32_t k = lane; k < span; k += 64) buf[k] = ob[base + k];
+        if (lane < BCJ_PIECE / 32) cand[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // candidate bitmap: lane marks its 16 bytes
+        {
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t i = 16 * lane + k;
+                const uint8_t b = buf[i];
+                if ((b == 0xE8 || b == 0xE9) && base + i <= limit && i < (uint32_t)BCJ_PIECE) m |= 1u << k;
+            }
+            if (m) atomicOr(&cand[lane >> 1], m << (16 * (lane & 1)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t w = 0; w < BCJ_PIECE / 32; w++) {
+            uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)cand[w]);
+            while (m) {
+                const uint32_t bitn = __builtin_ctz(m);
+                m &= m - 1;
+                const uint32_t li = 32 * w + bitn;                  // index inside the piece
+                const uint64_t i = base + li;
+                if (i < next_i) continue;                            // inside an operand that was converted
+                const uint32_t offset = now_pos0 + (uint32_t)i - prev_pos;
+                prev_pos = now_pos0 + (uint32_t)i;
+                if (offset > 5) prev_mask = 0;
+                else for (uint32_t k = 0; k < offset; k++) prev_mask = (prev_mask & 0x77) << 1;
+                uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)buf[li + 4]);
+                const bool allowed = (0x17u >> ((prev_mask >> 1) & 7)) & 1;   // t t t nil t nil nil nil
+                if ((b == 0x00 || b == 0xFF) && allowed && (prev_mask >> 1) < 0x10) {
+                    uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)((uint32_t)buf[li + 1] | ((uint32_t)buf[li + 2] << 8) | ((uint32_t)buf[li + 3] << 16) | (b << 24)));
+                    uint32_t dest;
+                    for (;;) {
+                        dest = src - (now_pos0 + (uint32_t)i + 5);
+                        if (prev_mask == 0) break;
+                        const uint32_t j = (0x33332210u >> (4 * (prev_mask >> 1))) & 15;   // 0 1 2 2 3 3 3 3
+                        b = (dest >> (24 - 8 * j)) & 0xFF;
+                        if (!(b == 0x00 || b == 0xFF)) break;
+                        src = dest ^ ((1u << (32 - 8 * j)) - 1);
+                    }
+                    if (lane == 0) {
+                        buf[li + 4] = (uint8_t)~(((dest >> 24) & 1) - 1);
+                        buf[li + 1] = (uint8_t)dest;
+                        buf[li + 2] = (uint8_t)(dest >> 8);
+                        buf[li + 3] = (uint8_t)(dest >> 16);
+                    }
+                    next_i = i + 5;
+                    prev_mask = 0;
+                } else {
+                    next_i = i + 1;
+                    prev_mask |= 1;
+                    if (b == 0x00 || b == 0xFF) prev_mask |= 0x10;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t k = lane; k < span; k += 64) ob[base + k] = buf[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// ---- delta filter inverse in place (xz.lisp:238-258) ----
+// out[i] = in[i] + out[i - d] (mod 256): an inclusive prefix sum along each residue class mod d.
+// One wave per unit; lane L owns the residues L, L + 64, ... < d and walks them serially.
+__global__ __launch_bounds__(64) void delta_kernel(const semz_unit *units, uint32_t nunits, uint8_t *out,
+                                                   const semz_result *results, int stage)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const semz_unit un = units[u];
+    const semz_result r = results[u];
+    if (r.status != SEMZ_OK || ((un.filters >> (4 * stage)) & 15) != SEMZ_FILTER_DELTA) return;
+    uint8_t *ob = out + r.out_off;
+    const uint64_t n = r.out_len;
+    int delta_index = 0;                               // delta stages before this one
+    for (int k = 0; k < stage; k++) delta_index += ((un.filters >> (4 * k)) & 15) == SEMZ_FILTER_DELTA;
+    const uint32_t d = 1 + ((un.param3 >> (8 * delta_index)) & 0xFF);
+    for (uint32_t res = lane; res < d; res += 64) {
+        uint8_t acc = 0;
+        for (uint64_t i = res; i < n; i += d) {
+            acc = (uint8_t)(acc + ob[i]);
+            ob[i] = acc;
+        }
+    }
+}
+
+} // namespace
+
+int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
+{
+    (void)in_len; (void)out_cap;
+    semz_span_begin(c, "lzma2_kernel");
+    lzma2_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails);
+    semz_span_end(c);
+    // filter chain stages (at most three non-last filters, xz.lisp:262); a kernel returns at once for
+    // units whose chain has another filter, or none, at that stage
+    semz_span_begin(c, "xz_filter_kernels");
+    for (int stage = 0; stage < 3; stage++) {
+        bcj_x86_kernel<<<nunits, 64, 0, c->stream>>>(d_units, nunits, d_out, d_results, stage);
+        delta_kernel<<<nunits, 64, 0, c->stream>>>(d_units, nunits, d_out, d_results, stage);
+    }
+    semz_span_end(c);
+    semz_span_begin(c, "checksum_kernel");
+    semz_launch_checksum(d_out, d_units, nunits, d_results, d_tails, c->d_tabs,
+                         (1u << SEMZ_TK_CRC32) | (1u << SEMZ_TK_CRC64) | (1u << SEMZ_TK_SHA256), c->stream);
+    semz_span_end(c);
+    return 0;
+}

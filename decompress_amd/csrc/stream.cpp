@@ -1,2 +1,486 @@
+// stream.cpp -- semz_decode_stream: decompress / decompress-all for a fully
+// buffered input (interface.lisp:149-208) on top of the batched unit decoder.
+//
+// Strategy for every format: find the units with the host splitter, decode all
+// of them in one device batch, then walk the container forward on the host in
+// exactly the order of the reference's `refill` state machine
+// (interface.lisp:91-133) and of its per-format states (gzip.lisp:89-115,
+// bzip2.lisp:456-503, xz.lisp:381-457, 166-233, 118-134), consuming the
+// already decoded units.  The walk reproduces "first error wins": a unit's
+// failure surfaces when the walk reaches it, outputs of earlier units stay
+// valid.  A unit the splitter did not predict (no index, a lying index, a
+// false magic) is decoded on demand as a batch of one.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+#include "container.h"
 #include "semz_host.h"
-extern "C" int semz_decode_stream(semz_ctx *, int, const uint8_t *, size_t, int, uint8_t **, size_t *, semz_result *, semz_stream_info *) { return -4; }
+
+using namespace semz;
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) return semz_fail(ctx, -2, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Span { uint64_t off, len; };
+
+struct Run {
+    semz_ctx *c;
+    const uint8_t *in;
+    size_t in_len;
+    uint8_t *d_in = nullptr;
+    uint8_t *d_out = nullptr;
+    size_t out_cap = 0, out_used = 0;          // device output arena; decoded spans are appended
+    semz_unit *d_units = nullptr;
+    semz_result *d_res = nullptr;
+    size_t unit_cap = 0;
+    std::vector<Span> spans;                   // output of the stream, in order, as arena spans
+
+    ~Run()
+    {
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_units) (void)hipFree(d_units);
+        if (d_res) (void)hipFree(d_res);
+    }
+    int open()
+    {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipMalloc((void **)&d_in, in_len + 64));
+        HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    }
+    // room for `need` more bytes at the end of the arena; keeps what is there
+    int reserve(size_t need)
+    {
+        if (out_used + need + 64 <= out_cap) return 0;
+        size_t ncap = (out_used + need + 64) * 3 / 2 + (1 << 20);
+        uint8_t *n = nullptr;
+        HIPCHK(c, hipMalloc((void **)&n, ncap));
+        if (out_used) HIPCHK(c, hipMemcpyAsync(n, d_out, out_used, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (d_out) HIPCHK(c, hipFree(d_out));
+        d_out = n;
+        out_cap = ncap;
+        return 0;
+    }
+    // decodes units (out_off relative to the arena, or SEMZ_OUT_AUTO packed from arena_base) into res
+    int decode(std::vector<semz_unit> &units, std::vector<semz_result> &res, uint64_t arena_base, uint64_t arena_room)
+    {
+        const size_t n = units.size();
+        res.assign(n, semz_result{});
+        if (!n) return 0;
+        if (n > unit_cap) {
+            if (d_units) HIPCHK(c, hipFree(d_units));
+            if (d_res) HIPCHK(c, hipFree(d_res));
+            d_units = nullptr; d_res = nullptr;
+            unit_cap = n + n / 2 + 16;
+            HIPCHK(c, hipMalloc((void **)&d_units, unit_cap * sizeof(semz_unit)));
+            HIPCHK(c, hipMalloc((void **)&d_res, unit_cap * sizeof(semz_result)));
+        }
+        HIPCHK(c, hipMemcpyAsync(d_units, units.data(), n * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_res, 0xFF, n * sizeof(semz_result), c->stream));
+        int rc = semz_decode_batch_device(c, units[0].kind, d_in, in_len, d_units, n, d_out + arena_base, arena_room, d_res);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(res.data(), d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP
+    int decode_one(semz_unit u, semz_result &r, uint64_t guess)
+    {
+        std::vector<semz_unit> us(1);
+        std::vector<semz_result> rs;
+        for (;;) {
+            int rc = reserve(guess);
+            if (rc) return rc;
+            u.out_off = u.out_off == SEMZ_OUT_AUTO ? SEMZ_OUT_AUTO : 0;
+            u.out_cap = guess;
+            us[0] = u;
+            rc = decode(us, rs, out_used, guess);
+            if (rc) return rc;
+            r = rs[0];
+            if (r.status != SEMZ_E_OUT_CAP || guess > (1ull << 40)) break;
+            guess *= 4;
+        }
+        r.out_off += out_used;                 // arena offset
+        if (r.status == SEMZ_OK) out_used += r.out_len;
+        return 0;
+    }
+    void emit(uint64_t off, uint64_t len)
+    {
+        if (!len) return;
+        if (!spans.empty() && spans.back().off + spans.back().len == off) spans.back().len += len;
+        else spans.push_back(Span{off, len});
+    }
+    int gather(uint8_t **out, size_t *out_len)
+    {
+        size_t total = 0;
+        for (auto &s : spans) total += s.len;
+        uint8_t *h = (uint8_t *)malloc(total ? total : 1);
+        if (!h) return semz_fail(c, -5, "out of host memory (%zu bytes)", total);
+        size_t at = 0;
+        for (auto &s : spans) {
+            hipError_t e = hipMemcpyAsync(h + at, d_out + s.off, s.len, hipMemcpyDeviceToHost, c->stream);
+            if (e != hipSuccess) { free(h); return semz_fail(c, -2, "download: %s", hipGetErrorString(e)); }
+            at += s.len;
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { free(h); return semz_fail(c, -2, "sync failed"); }
+        *out = h;
+        *out_len = total;
+        return 0;
+    }
+};
+
+struct Outcome { int status = SEMZ_OK; uint32_t detail = 0; uint64_t consumed = 0; };
+
+// ---- deflate / zlib / gzip ----
+int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *info)
+{
+    const uint32_t kind = fmt == SEMZ_FMT_GZIP ? SEMZ_UNIT_GZIP : fmt == SEMZ_FMT_ZLIB ? SEMZ_UNIT_ZLIB : SEMZ_UNIT_DEFLATE;
+    // predecode: BGZF-indexed gzip members
+    std::map<uint64_t, semz_result> pre;
+    if (fmt == SEMZ_FMT_GZIP && all_members) {
+        semz_unit *su = nullptr;
+        size_t sn = 0;
+        semz_stream_info si;
+        if (semz_split(fmt, R.in, R.in_len, nullptr, nullptr, 0, &su, &sn, &si) == 0 && si.reserved > 1) {
+            std::vector<semz_unit> units(su, su + si.reserved);   // members whose size the BGZF index gives
+            uint64_t total = 0;
+            for (auto &u : units) total += u.out_cap;
+            int rc = R.reserve(total);
+            if (rc) { free(su); return rc; }
+            std::vector<semz_result> res;
+            rc = R.decode(units, res, R.out_used, total);
+            if (rc) { free(su); return rc; }
+            for (size_t i = 0; i < units.size(); i++) {
+                res[i].out_off += R.out_used;
+                pre[units[i].in_off] = res[i];
+            }
+            R.out_used += total;
+        }
+        free(su);
+    }
+    uint64_t pos = 0;
+    for (uint32_t member = 0;; member++) {
+        semz_result r;
+        auto it = pre.find(pos);
+        if (it != pre.end()) r = it->second;
+        else {
+            semz_unit u{};
+            u.kind = kind;
+            u.in_off = pos;
+            u.in_limit = R.in_len;
+            uint64_t guess = (R.in_len - pos) * 6 + 65536;
+            int rc = R.decode_one(u, r, guess);
+            if (rc) return rc;
+        }
+        if (member == 0 && info) {
+            if (fmt == SEMZ_FMT_ZLIB) info->first_header[3] = r.aux;
+            info->nmembers = 0;
+        }
+        oc.consumed = pos + ((r.in_end_bit - 8 * pos + 7) >> 3);
+        if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
+        R.emit(r.out_off, r.out_len);
+        if (info) info->nmembers = member + 1;
+        pos = oc.consumed;
+        if (!all_members || pos == R.in_len) return 0;            // buffer-stream-check-eof, interface.lisp:110-112
+        if (fmt != SEMZ_FMT_GZIP) { oc.status = SEMZ_E_TRAILING_DATA; return 0; }   // interface.lisp:125-130
+    }
+}
+
+// ---- bzip2 ----
+int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
+{
+    std::vector<BzCandidate> cand = scan_bzip2(R.in, R.in_len);
+    std::vector<semz_unit> units;
+    std::vector<uint64_t> start_bits;
+    uint64_t guess = 0;
+    for (auto &x : cand) {
+        if (x.footer) continue;
+        semz_unit u{};
+        u.kind = SEMZ_UNIT_BZIP2_BLOCK;
+        u.in_off = x.bit >> 3;
+        u.in_bit_off = (uint32_t)(x.bit & 7);
+        u.in_limit = R.in_len;
+        u.out_off = SEMZ_OUT_AUTO;
+        u.param0 = x.level;
+        units.push_back(u);
+        start_bits.push_back(x.bit);
+        guess += (uint64_t)x.level * 100000 + 4096;
+    }
+    std::map<uint64_t, size_t> by_bit;
+    std::vector<semz_result> res;
+    uint64_t arena0 = R.out_used;
+    for (;;) {
+        int rc = R.reserve(guess);
+        if (rc) return rc;
+        rc = R.decode(units, res, arena0, guess);
+        if (rc) return rc;
+        bool cap = false;
+        for (auto &r : res) cap = cap || r.status == SEMZ_E_OUT_CAP;
+        if (!cap || guess > (1ull << 40)) break;
+        guess *= 4;                                               // RLE1 can expand far beyond the block size
+    }
+    for (size_t i = 0; i < units.size(); i++) {
+        by_bit[start_bits[i]] = i;
+        if (res[i].status == SEMZ_OK) R.out_used = arena0 + res[i].out_off + res[i].out_len > R.out_used ? arena0 + res[i].out_off + res[i].out_len : R.out_used;
+    }
+    // forward walk (bzip2.lisp:425-503)
+    uint64_t pos = 0;
+    for (uint32_t member = 0;; member++) {
+        uint32_t level = 0, det = 0;
+        int st = parse_bzip2_header(R.in, pos, R.in_len, &level, &det);
+        if (member == 0 && info) { info->first_header[0] = level; info->status = st; info->detail = det; }
+        if (st != SEMZ_OK) {
+            oc.status = st; oc.detail = det;
+            oc.consumed = st == SEMZ_EOF ? R.in_len : pos + (st == SEMZ_E_BZ_MAGIC ? 2 : 4);
+            return 0;
+        }
+        uint64_t bit = 8 * (pos + 4);
+        uint32_t stream_crc = 0;
+        for (;;) {
+            if (8 * R.in_len - bit < 48) { oc.status = SEMZ_EOF; oc.consumed = R.in_len; return 0; }
+            const uint64_t magic = read_bits_be(R.in, R.in_len, bit, 48);
+            if (magic == BZ_BLOCK_MAGIC) {
+                semz_result r;
+                auto it = by_bit.find(bit);
+                if (it != by_bit.end() && units[it->second].param0 == level) {
+                    r = res[it->second];
+                    r.out_off += arena0;
+                } else {
+                    semz_unit u{};
+                    u.kind = SEMZ_UNIT_BZIP2_BLOCK;
+                    u.in_off = bit >> 3;
+                    u.in_bit_off = (uint32_t)(bit & 7);
+                    u.in_limit = R.in_len;
+                    u.out_off = SEMZ_OUT_AUTO;
+                    u.param0 = level;
+                    int rc = R.decode_one(u, r, (uint64_t)level * 100000 * 2);
+                    if (rc) return rc;
+                }
+                if (r.status != SEMZ_OK) {
+                    oc.status = r.status; oc.detail = r.detail; oc.consumed = (r.in_end_bit + 7) >> 3;
+                    return 0;
+                }
+                R.emit(r.out_off, r.out_len);
+                const uint32_t crc = (uint32_t)r.check[0] | ((uint32_t)r.check[1] << 8) | ((uint32_t)r.check[2] << 16) | ((uint32_t)r.check[3] << 24);
+                stream_crc = ((stream_crc << 1) | (stream_crc >> 31)) ^ crc;      // bzip2.lisp:44-47
+                bit = r.in_end_bit;
+            } else if (magic == BZ_FOOTER_MAGIC) {
+                bit += 48;
+                if (8 * R.in_len - bit < 32) { oc.status = SEMZ_EOF; oc.consumed = R.in_len; return 0; }
+                const uint32_t want = (uint32_t)read_bits_be(R.in, R.in_len, bit, 32);
+                bit += 32;
+                if (want != stream_crc) { oc.status = SEMZ_E_BZ_STREAM_CRC; oc.detail = want; oc.consumed = (bit + 7) >> 3; return 0; }
+                break;
+            } else {
+                oc.status = SEMZ_E_BZ_BLOCK_MAGIC; oc.consumed = (bit + 48 + 7) >> 3;
+                return 0;
+            }
+        }
+        pos = (bit + 7) >> 3;                                     // flush-byte, bzip2.lisp:497
+        oc.consumed = pos;
+        if (info) info->nmembers = member + 1;
+        if (!all_members || pos == R.in_len) return 0;
+    }
+}
+
+// ---- xz ----
+int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
+{
+    // predecode everything the index promises
+    std::map<uint64_t, std::pair<semz_unit, semz_result>> pre;   // keyed by the offset of the LZMA2 data
+    {
+        semz_unit *su = nullptr;
+        size_t sn = 0;
+        semz_stream_info si;
+        if (semz_split(SEMZ_FMT_XZ, R.in, R.in_len, nullptr, nullptr, 0, &su, &sn, &si) == 0 && sn) {
+            std::vector<semz_unit> units(su, su + sn);
+            int rc = R.reserve(si.total_out);
+            if (rc) { free(su); return rc; }
+            std::vector<semz_result> res;
+            rc = R.decode(units, res, R.out_used, si.total_out);
+            if (rc) { free(su); return rc; }
+            for (size_t i = 0; i < sn; i++) {
+                res[i].out_off += R.out_used;
+                pre[units[i].in_off] = std::make_pair(units[i], res[i]);
+            }
+            R.out_used += si.total_out;
+        }
+        free(su);
+    }
+    const uint8_t *in = R.in;
+    const uint64_t n = R.in_len;
+    uint64_t pos = 0;
+    bool skip_magic = false;
+    auto fail = [&](int st, uint32_t d, uint64_t at) { oc.status = st; oc.detail = d; oc.consumed = at; return 0; };
+    for (uint32_t member = 0;; member++) {
+        uint32_t ct = 0, det = 0;
+        uint64_t hend = 0;
+        int st = parse_xz_stream_header(in, pos, n, skip_magic, &ct, &hend, &det);
+        if (member == 0 && info) { info->first_header[0] = ct; info->status = st; info->detail = det; }
+        if (st != SEMZ_OK) return fail(st, det, hend);
+        pos = hend;
+        const uint32_t stream_flags = (uint32_t)ct << 8;
+        std::vector<std::pair<uint64_t, uint64_t>> seen;          // (unpadded size, uncompressed size)
+        for (;;) {                                                // :block/index, xz.lisp:389-407
+            if (pos >= n) return fail(SEMZ_EOF, 0, n);
+            if (in[pos] == 0) { pos++; break; }
+            XzBlockHeader h = parse_xz_block_header(in, pos, n);
+            if (h.status != SEMZ_OK) return fail(h.status, h.detail, h.status == SEMZ_EOF ? n : pos + h.header_size + 4);
+            const uint64_t data = pos + h.header_size + 4;
+            semz_unit u{};
+            u.kind = SEMZ_UNIT_XZ_BLOCK;
+            u.in_off = data;
+            u.in_limit = n;
+            u.flags = (h.have_csize ? SEMZ_UF_HAVE_IN_SIZE : 0) | (h.have_usize ? SEMZ_UF_HAVE_OUT_SIZE : 0);
+            u.size_in = h.csize; u.size_out = h.usize;
+            u.param0 = h.dict_size; u.param1 = ct; u.param2 = h.bcj_offset; u.param3 = h.delta_dists; u.filters = h.filters;
+            semz_result r;
+            auto it = pre.find(data);
+            bool reuse = false;
+            if (it != pre.end()) {
+                const semz_unit &q = it->second.first;
+                reuse = q.flags == u.flags && q.size_in == u.size_in && q.size_out == u.size_out && q.param0 == u.param0 &&
+                        q.param1 == u.param1 && q.param2 == u.param2 && q.param3 == u.param3 && q.filters == u.filters &&
+                        it->second.second.status != SEMZ_E_OUT_CAP;
+            }
+            if (reuse) r = it->second.second;
+            else {
+                uint64_t guess = h.have_usize && h.usize < (1ull << 40) ? h.usize : (n - data) * 8 + (1 << 20);
+                int rc = R.decode_one(u, r, guess);
+                if (rc) return rc;
+                if (r.status == SEMZ_E_OUT_CAP && h.have_usize) {
+                    // the declared size was too small for what the block holds: decode on to find the
+                    // error the reference reports (a size mismatch at block end, or an earlier one)
+                    rc = R.decode_one(u, r, (n - data) * 8 + (1 << 20));
+                    if (rc) return rc;
+                }
+            }
+            if (r.status != SEMZ_OK) return fail(r.status, r.detail, (r.in_end_bit + 7) >> 3);
+            R.emit(r.out_off, r.out_len);
+            const uint64_t real_csize = ((uint64_t)r.detail << 32) | r.aux;
+            seen.emplace_back(h.header_size + 4 + real_csize + xz_check_size(ct), r.out_len);
+            pos = r.in_end_bit >> 3;
+        }
+        // finish-xz-member: index and footer (xz.lisp:166-233)
+        {
+            const uint64_t idx0 = pos - 1;
+            std::vector<uint8_t> ridx;
+            ridx.push_back(0);
+            auto push = [&](uint64_t v) {
+                for (;;) {
+                    ridx.push_back((uint8_t)(v & 0x7F));
+                    v >>= 7;
+                    if (!v) return;
+                    ridx.back() |= 0x80;
+                }
+            };
+            uint64_t count, a, b;
+            auto vfail = [&](int s) { return fail(s, 0, s == SEMZ_EOF ? n : pos); };
+            if ((st = xz_varint(in, &pos, n, &count)) != SEMZ_OK) return vfail(st);
+            push(count);
+            bool mism = false;
+            for (uint64_t k = 0; k < count; k++) {
+                if ((st = xz_varint(in, &pos, n, &a)) != SEMZ_OK) return vfail(st);
+                if ((st = xz_varint(in, &pos, n, &b)) != SEMZ_OK) return vfail(st);
+                push(a);
+                push(b);
+                if (k < seen.size() && (a != seen[k].first || b != seen[k].second)) mism = true;
+            }
+            while (ridx.size() & 3) {
+                if (pos >= n) return fail(SEMZ_EOF, 0, n);
+                if (in[pos++] != 0) return fail(SEMZ_E_XZ_INDEX_PADDING, 0, pos);
+                ridx.push_back(0);
+            }
+            if (count != seen.size()) return fail(SEMZ_E_XZ_INDEX_COUNT, 0, pos);
+            if (mism) return fail(SEMZ_E_XZ_INDEX_SIZES, 0, pos);
+            if (n - pos < 4) return fail(SEMZ_EOF, 0, n);
+            const uint32_t icrc = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
+            pos += 4;
+            if (icrc != crc32_host(ridx.data(), ridx.size())) return fail(SEMZ_E_XZ_INDEX_CRC, icrc, pos);
+            if (n - pos < 12) return fail(SEMZ_EOF, 0, n);
+            const uint8_t *f = in + pos;
+            pos += 12;
+            const uint32_t fcrc = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
+            const uint32_t bsz = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
+            if (fcrc != crc32_host(f + 4, 6)) return fail(SEMZ_E_XZ_FOOTER_CRC, fcrc, pos);
+            if (4ull * ((uint64_t)bsz + 1) != 4 + ridx.size()) return fail(SEMZ_E_XZ_BACKWARD_SIZE, 0, pos);
+            if (stream_flags != ((uint32_t)f[8] | ((uint32_t)f[9] << 8))) return fail(SEMZ_E_XZ_FOOTER_FLAGS, 0, pos);
+            if (f[10] != 0x59 || f[11] != 0x5A) return fail(SEMZ_E_XZ_FOOTER_MAGIC, 0, pos);
+            (void)idx0;
+        }
+        oc.consumed = pos;
+        if (info) info->nmembers = member + 1;
+        if (!all_members || pos == n) return 0;
+        // make-reset-state: stream padding, then the next member (xz.lisp:118-134)
+        for (;;) {
+            const uint64_t left = n - pos;
+            if (left == 0) { oc.consumed = n; return 0; }
+            if (left < 4) return fail(SEMZ_E_XZ_PADDING, 0, pos);
+            const uint8_t *b = in + pos;
+            pos += 4;
+            if (b[0] | b[1] | b[2] | b[3]) {
+                if (b[0] == 0xFD && b[1] == 0x37 && b[2] == 0x7A && b[3] == 0x58) {
+                    if (pos >= n) return fail(SEMZ_EOF, 0, n);
+                    if (in[pos++] == 0x5A) {
+                        if (pos >= n) return fail(SEMZ_EOF, 0, n);
+                        if (in[pos++] == 0x00) { skip_magic = true; break; }
+                    }
+                }
+                return fail(SEMZ_E_XZ_TRAILING_GARBAGE, 0, pos);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t **out,
+                                  size_t *out_len, semz_result *res, semz_stream_info *info)
+{
+    if (!c) return -1;
+    if (!out || !out_len || !res || (!in && in_len)) return semz_fail(c, -1, "null pointer");
+    *out = nullptr;
+    *out_len = 0;
+    memset(res, 0, sizeof *res);
+    semz_stream_info si;
+    memset(&si, 0, sizeof si);
+    Run R{c, in, in_len};
+    int rc = R.open();
+    if (rc) return rc;
+    Outcome oc;
+    switch (fmt) {
+    case SEMZ_FMT_DEFLATE:
+    case SEMZ_FMT_ZLIB:
+    case SEMZ_FMT_GZIP: {
+        // header information of the first member (interface.lisp:118-122)
+        semz_unit *su = nullptr;
+        size_t sn = 0;
+        static const uint64_t zero = 0;
+        if (semz_split(fmt, in, in_len, &zero, nullptr, 1, &su, &sn, &si) == 0) free(su);
+        rc = run_deflate_family(R, fmt, all_members != 0, oc, &si);
+        break;
+    }
+    case SEMZ_FMT_BZIP2: rc = run_bzip2(R, all_members != 0, oc, &si); break;
+    case SEMZ_FMT_XZ: rc = run_xz(R, all_members != 0, oc, &si); break;
+    default: return semz_fail(c, -1, "format %d has no stream decoder yet", fmt);
+    }
+    if (rc) return rc;
+    rc = R.gather(out, out_len);
+    if (rc) return rc;
+    res->status = oc.status;
+    res->detail = oc.detail;
+    res->in_end_bit = 8 * oc.consumed;
+    res->out_len = *out_len;
+    si.total_out = *out_len;
+    if (info) *info = si;
+    return 0;
+}

@@ -58,11 +58,12 @@ enum {
 /* semz_unit.flags */
 enum {
     SEMZ_UF_HAVE_DICT_FN = 1u << 0,  /* zlib: caller has a dictionary function (zlib.lisp:43-44) */
-    SEMZ_UF_BCJ_X86 = 1u << 1,       /* xz: x86 BCJ filter precedes LZMA2 (xz.lisp:323-344) */
     SEMZ_UF_HAVE_IN_SIZE = 1u << 2,  /* xz: block header declares a compressed size */
-    SEMZ_UF_HAVE_OUT_SIZE = 1u << 3, /* xz: block header declares an uncompressed size */
-    SEMZ_UF_DELTA = 1u << 4          /* xz: delta filter precedes LZMA2 (param3 = distance) */
+    SEMZ_UF_HAVE_OUT_SIZE = 1u << 3  /* xz: block header declares an uncompressed size */
 };
+
+/* xz filters that follow LZMA2 when decoding (semz_unit.filters, xz.lisp:311-344) */
+enum { SEMZ_FILTER_END = 0, SEMZ_FILTER_DELTA = 1, SEMZ_FILTER_X86 = 2 };
 
 /* xz check types (xz.lisp:12-31) */
 enum { SEMZ_CHECK_NONE = 0, SEMZ_CHECK_CRC32 = 1, SEMZ_CHECK_CRC64 = 4, SEMZ_CHECK_SHA256 = 10 };
@@ -86,9 +87,11 @@ typedef struct semz_unit {
     uint32_t in_bit_off;  /* bzip2: bit offset 0..7 (MSB-first) of the magic inside byte in_off */
     uint32_t param0;      /* deflate: window size (0 = 32768); bzip2: level 1..9; lzma2/xz: dictionary size */
     uint32_t param1;      /* xz: check type */
-    uint32_t param2;      /* xz: BCJ start offset (xz.lisp:326-331) */
-    uint32_t param3;      /* xz: delta distance 1..256 */
-    uint32_t reserved;
+    uint32_t param2;      /* xz: x86 BCJ start offset (xz.lisp:326-331) */
+    uint32_t param3;      /* xz: delta distances minus one, 8 bits per delta stage in chain order */
+    uint32_t filters;     /* xz: filter chain applied to the LZMA2 output, 4 bits per stage
+                             (SEMZ_FILTER_*), first applied stage in bits 3:0; in the block header
+                             that is the filter listed just before LZMA2 (xz.lisp:311-312) */
     uint64_t prefix_off;  /* deflate/zlib preset history: span inside `in` (deflate.lisp:419-425) */
     uint64_t prefix_len;
     uint64_t size_in;     /* xz: declared compressed size (SEMZ_UF_HAVE_IN_SIZE) */
@@ -179,7 +182,7 @@ typedef struct semz_stream_info {
     uint64_t total_out;     /* sum of out_cap over units when known, else 0 */
     uint32_t first_header[8];/* format-specific first-member header words, see INTEGRATION.md */
     uint32_t nmembers;      /* streams/members seen (bzip2, xz) */
-    uint32_t reserved;
+    uint32_t reserved;      /* semz_split, deflate family: leading units whose output size is known */
 } semz_stream_info;
 
 int semz_split(int fmt, const uint8_t *in, size_t in_len,

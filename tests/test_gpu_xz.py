@@ -1,0 +1,146 @@
+"""GPU parity: xz blocks / raw LZMA2 through the C ABI vs the CPU oracle (bit-exact)."""
+import lzma
+import random
+
+import pytest
+
+import corpus
+import xzutil
+from decompress_amd import _lib
+from oracle import oracle
+from test_split import split
+
+pytestmark = pytest.mark.gpu
+
+
+def decode_units(engine, data, units, cap):
+    out, res = engine.decode_batch(data, units, cap)
+    return out, res
+
+
+def check_xz(engine, data, expect=None):
+    """Splits with the product splitter, decodes the blocks as one batch, compares with the oracle's
+    member-level result (the blocks of a valid member concatenate to its output)."""
+    units, info = split(_lib.FMT_XZ, data)
+    er, eo = oracle.decompress(8, data, True, cap=(len(expect) if expect is not None else 1 << 22) + 16)
+    assert units, "splitter found no blocks"
+    cap = sum(u.out_cap for u in units)
+    out, res = decode_units(engine, data, units, cap + 16)
+    got = b"".join(out.raw[r.out_off:r.out_off + r.out_len] for r in res)
+    if er.status == 0:
+        assert all(r.status == 0 for r in res), [(r.status, r.detail) for r in res]
+        assert got == eo
+        if expect is not None:
+            assert got == expect
+    else:
+        bad = [r for r in res if r.status != 0]
+        assert bad and bad[0].status == er.status, ([r.status for r in res], er.status)
+    return res
+
+
+@pytest.mark.parametrize("check", [lzma.CHECK_NONE, lzma.CHECK_CRC32, lzma.CHECK_CRC64, lzma.CHECK_SHA256])
+def test_single_block_members(engine, check):
+    rng = random.Random(check)
+    for i, gen in enumerate([corpus.text, corpus.random_bytes, corpus.repetitive, corpus.mixed, corpus.x86ish]):
+        n = rng.choice([1, 3000, 70000, 300000])
+        d = gen(n, seed=7 * i + check)
+        for filters in ([{"id": lzma.FILTER_LZMA2, "preset": rng.choice([0, 3, 6, 9])}],
+                        [{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_LZMA2, "preset": 6}],
+                        [{"id": lzma.FILTER_DELTA, "dist": rng.choice([1, 4, 256])},
+                         {"id": lzma.FILTER_LZMA2, "preset": 6, "lc": 1, "lp": 2, "pb": 1}],
+                        [{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_DELTA, "dist": 3},
+                         {"id": lzma.FILTER_LZMA2, "preset": 2, "lc": 0, "lp": 4, "pb": 4}]):
+            res = check_xz(engine, xzutil.xz_py(d, check, filters), d)
+            want_len = {lzma.CHECK_NONE: 0, lzma.CHECK_CRC32: 4, lzma.CHECK_CRC64: 8, lzma.CHECK_SHA256: 32}[check]
+            assert res[0].check_len == want_len
+
+
+def test_multi_block_x86_crc64_and_sha256(engine):
+    d = corpus.x86ish(1_500_000, seed=5)
+    for chk in ("crc64", "sha256"):
+        data = xzutil.xz_cli(d, "--block-size=262144", "--x86", "--lzma2=preset=6", f"--check={chk}")
+        res = check_xz(engine, data, d)
+        assert len(res) == 6
+
+
+def test_one_mib_blocks(engine):
+    d = corpus.text(3 << 20, seed=6)
+    data = xzutil.xz_cli(d, "--block-size=1MiB", "--lzma2=preset=6", "--check=crc64")
+    res = check_xz(engine, data, d)
+    assert len(res) == 3 and all(r.out_len == 1 << 20 for r in res)
+
+
+def test_reference_lol_vector(engine):
+    # README.org:306-308: LZMA chunk -> stored chunks -> LZMA chunk without state reset
+    import base64
+    data = base64.b64decode("/Td6WFoAAAD/EtlBAgAhAQoAAABTxyq54AAAAAUJACX//AAAAgAAT4AAAAAFACfRR0AAAAABKAM7StLkBnKeegEAAAAAAFla")
+    check_xz(engine, data, b"LOL")
+
+
+def test_raw_lzma2_units(engine):
+    items = []
+    for i, n in enumerate([1, 500, 40000, 200000]):
+        d = corpus.mixed(n, seed=i)
+        f = [{"id": lzma.FILTER_LZMA2, "preset": 6, "dict_size": 1 << 20}]
+        items.append((lzma.compress(d, lzma.FORMAT_RAW, filters=f), d))
+    data = b"".join(b for b, _ in items)
+    units, off, ooff = [], 0, 0
+    for b, d in items:
+        units.append(_lib.Unit(in_off=off, in_limit=off + len(b), out_off=ooff, out_cap=len(d), kind=_lib.UNIT_LZMA2,
+                               param0=1 << 20))
+        off += len(b)
+        ooff += len(d)
+    out, res = engine.decode_batch(data, units, ooff)
+    for u, r, (b, d) in zip(units, res, items):
+        er, eo = oracle.lzma2(b, 1 << 20, cap=len(d))
+        assert r.status == er.status == 0
+        assert out.raw[u.out_off:u.out_off + r.out_len] == eo == d
+        assert r.in_end_bit - 8 * u.in_off == er.in_end_bit
+
+
+def test_corrupt_and_truncated_lzma2(engine):
+    rng = random.Random(3)
+    d = corpus.mixed(60000, seed=9)
+    f = [{"id": lzma.FILTER_LZMA2, "preset": 4, "dict_size": 1 << 16}]
+    base = lzma.compress(d, lzma.FORMAT_RAW, filters=f)
+    blobs = [base[:cut] for cut in (0, 1, 3, 7, len(base) // 2, len(base) - 1)]
+    for _ in range(80):
+        b = bytearray(base)
+        for _ in range(rng.choice([1, 1, 2, 4])):
+            b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        blobs.append(bytes(b))
+    # small dictionary: distances beyond it are rejected (lzma.lisp:604-605)
+    data = b"".join(blobs)
+    units, off = [], 0
+    for i, b in enumerate(blobs):
+        units.append(_lib.Unit(in_off=off, in_limit=off + len(b), out_off=i * 70000, out_cap=66000, kind=_lib.UNIT_LZMA2,
+                               param0=(1 << 16) if i % 3 else 4096))
+        off += len(b)
+    out, res = engine.decode_batch(data, units, len(blobs) * 70000)
+    for u, r, b in zip(units, res, blobs):
+        er, eo = oracle.lzma2(b, u.param0, cap=66000)
+        assert r.status == er.status, (len(b), r.status, er.status, r.detail, er.detail)
+        if er.status == 0:
+            assert out.raw[u.out_off:u.out_off + r.out_len] == eo
+            assert r.in_end_bit - 8 * u.in_off == er.in_end_bit
+        else:
+            assert r.detail == er.detail
+
+
+def test_corrupt_xz_blocks(engine):
+    rng = random.Random(5)
+    d = corpus.x86ish(50000, seed=2)
+    base = xzutil.xz_py(d, lzma.CHECK_CRC32, [{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_LZMA2, "preset": 3}])
+    units0, _ = split(_lib.FMT_XZ, base)
+    data_lo = units0[0].in_off
+    for t in range(40):
+        b = bytearray(base)
+        for _ in range(rng.choice([1, 2])):
+            b[rng.randrange(data_lo, len(b) - 24)] ^= 1 << rng.randrange(8)     # payload, padding or check
+        data = bytes(b)
+        u = units0[0]
+        out, res = engine.decode_batch(data, [u], u.out_cap + 16)
+        er, eo = oracle.decompress(8, data, True, cap=len(d) + 16)
+        assert res[0].status == er.status, (t, res[0].status, er.status)
+        if er.status == 0:
+            assert out.raw[:res[0].out_len] == eo
