@@ -48,46 +48,95 @@ def _make_zlib_records(args):
     return [zlib.compress(big[k * unit_bytes:(k + 1) * unit_bytes], 6) for k in range(hi - lo)]
 
 
-def build_workload(fmt, nunits, unit_bytes, seed, workers):
-    """Returns (input bytes, [Unit], total_out, total_in, kind)."""
-    from decompress_amd import _lib
-    step = max(1, nunits // (workers * 4))
-    jobs = [(lo, min(nunits, lo + step), unit_bytes, seed) for lo in range(0, nunits, step)]
-    fn = _make_gzip_members if fmt == "gzip" else _make_zlib_records
+def _make_bzip2_streams(args):
+    """bzip2 -9 streams of `unit_bytes` each (several 900k blocks per stream)."""
+    import bz2
+    import corpus
+    lo, hi, unit_bytes, seed = args
+    return [bz2.compress(corpus.text(unit_bytes, seed=seed + i), 9) for i in range(lo, hi)]
+
+
+def _make_xz_streams(args):
+    """xz streams with 1 MiB blocks, x86 BCJ + LZMA2 preset 6, CRC64 (or SHA-256 when seed is odd... no: see check)."""
+    import subprocess
+    import corpus
+    lo, hi, unit_bytes, seed, check = args
+    out = []
+    for i in range(lo, hi):
+        d = corpus.x86ish(unit_bytes, seed=seed + i)
+        out.append(subprocess.run(["xz", "-c", "-T1", "--block-size=1MiB", "--x86", "--lzma2=preset=6", f"--check={check}"],
+                                  input=d, stdout=subprocess.PIPE, check=True).stdout)
+    return out
+
+
+def _pool_map(fn, jobs, workers):
     if workers > 1:
         with mp.get_context("fork").Pool(workers) as pool:
-            parts = pool.map(fn, jobs)
-    else:
-        parts = [fn(j) for j in jobs]
+            return pool.map(fn, jobs)
+    return [fn(j) for j in jobs]
+
+
+def _split(fmt_id, data):
+    """Units of a container through the product's host splitter (semz_split)."""
+    from decompress_amd import _lib
+    lib = _lib.load()
+    units = C.POINTER(_lib.Unit)()
+    n = C.c_size_t()
+    info = _lib.StreamInfo()
+    rc = lib.semz_split(fmt_id, data, len(data), None, None, 0, C.byref(units), C.byref(n), C.byref(info))
+    assert rc == 0
+    arr = (_lib.Unit * n.value)()
+    C.memmove(arr, units, C.sizeof(_lib.Unit) * n.value)
+    lib.semz_free(units)
+    return arr, info
+
+
+def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64"):
+    """Returns dict(data, uarr, nunits, total_out, total_in, kind, blobs, out_cap)."""
+    from decompress_amd import _lib
+    if fmt in ("gzip", "zlib"):
+        step = max(1, nunits // (workers * 4))
+        jobs = [(lo, min(nunits, lo + step), unit_bytes, seed) for lo in range(0, nunits, step)]
+        parts = _pool_map(_make_gzip_members if fmt == "gzip" else _make_zlib_records, jobs, workers)
+        blobs = [b for p in parts for b in p]
+        kind = _lib.UNIT_GZIP if fmt == "gzip" else _lib.UNIT_ZLIB
+        data = b"".join(blobs)
+        uarr = (_lib.Unit * nunits)()
+        off = 0
+        for i, b in enumerate(blobs):
+            # all-members semantics: a gzip member may look ahead to the end of the input
+            lim = len(data) if fmt == "gzip" else off + len(b)
+            uarr[i] = _lib.Unit(in_off=off, in_limit=lim, out_off=i * unit_bytes, out_cap=unit_bytes, kind=kind)
+            off += len(b)
+        return dict(data=data, uarr=uarr, nunits=nunits, total_out=nunits * unit_bytes, total_in=len(data), kind=kind,
+                    blobs=blobs, out_cap=nunits * unit_bytes, sample_out=unit_bytes)
+    # bzip2 / xz: `nunits` streams of `unit_bytes`; the blocks inside are found by the host splitter
+    jobs = [(i, i + 1, unit_bytes, seed) + ((check,) if fmt == "xz" else ()) for i in range(nunits)]
+    parts = _pool_map(_make_bzip2_streams if fmt == "bzip2" else _make_xz_streams, jobs, workers)
     blobs = [b for p in parts for b in p]
-    kind = _lib.UNIT_GZIP if fmt == "gzip" else _lib.UNIT_ZLIB
     data = b"".join(blobs)
-    units, off = [], 0
-    for i, b in enumerate(blobs):
-        # all-members semantics: a member may look ahead to the end of the input
-        lim = len(data) if fmt == "gzip" else off + len(b)
-        units.append(_lib.Unit(in_off=off, in_limit=lim, out_off=i * unit_bytes, out_cap=unit_bytes, kind=kind))
-        off += len(b)
-    return data, units, nunits * unit_bytes, len(data), kind, blobs
+    uarr, info = _split(_lib.FMT_BZIP2 if fmt == "bzip2" else _lib.FMT_XZ, data)
+    total_out = nunits * unit_bytes
+    kind = _lib.UNIT_BZIP2_BLOCK if fmt == "bzip2" else _lib.UNIT_XZ_BLOCK
+    return dict(data=data, uarr=uarr, nunits=len(uarr), total_out=total_out, total_in=len(data), kind=kind, blobs=blobs,
+                out_cap=total_out + 4096, sample_out=unit_bytes)
 
 
-def cpu_baseline(fmt, blobs, unit_bytes, budget_s=12.0):
+def cpu_baseline(fmt, blobs, sample_out, budget_s=12.0):
     """Oracle (CPU port of the reference algorithm) on a bounded sample, one core."""
     from oracle import oracle
+    fmt_id = {"gzip": 2, "zlib": 1, "bzip2": 3, "xz": 8}[fmt]
     t0 = time.perf_counter()
     done = 0
     for b in blobs:
-        if fmt == "gzip":
-            r, o, _ = oracle.gzip_member(b, unit_bytes)
-        else:
-            r, o, _ = oracle.zlib_member(b, False, None, unit_bytes)
-        assert r.status == 0 and len(o) == unit_bytes
+        r, o = oracle.decompress(fmt_id, b, True, cap=sample_out + 16)
+        assert r.status == 0 and len(o) == sample_out
         done += 1
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": done * unit_bytes / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{done} of the same {fmt} units ({done * unit_bytes / 2**20:.0f} MiB out) through oracle/ "
+    return {"value": done * sample_out / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{done} of the same {fmt} inputs ({done * sample_out / 2**20:.0f} MiB out) through oracle/ "
                       f"(C restatement of the reference), 1 thread, {dt:.1f} s"}
 
 
@@ -96,9 +145,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--format", default="gzip", choices=["gzip", "zlib"])
+    ap.add_argument("--format", default="gzip", choices=["gzip", "zlib", "bzip2", "xz"])
     ap.add_argument("--units", type=int, default=0)
     ap.add_argument("--unit-bytes", type=int, default=0)
+    ap.add_argument("--check", default="crc64", choices=["crc64", "sha256", "crc32", "none"])
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
 
@@ -110,16 +160,25 @@ def main():
     if a.format == "gzip":
         nunits, unit_bytes = a.units or 4096, a.unit_bytes or 262144
         workload = f"{nunits} independent {unit_bytes // 1024} KiB gzip -6 members per GPU (BASELINE configs[1]), CRC-32 + ISIZE verified"
-    else:
+    elif a.format == "zlib":
         nunits, unit_bytes = a.units or (1 << 18), a.unit_bytes or 4096
         workload = f"{nunits} zlib -6 records of {unit_bytes} B per GPU (BASELINE configs[4] shape), Adler-32 verified"
+    elif a.format == "bzip2":
+        nunits, unit_bytes = a.units or 8, a.unit_bytes or (64 << 20)
+        workload = (f"{nunits} bzip2 -9 streams of {unit_bytes >> 20} MiB per GPU, block-parallel "
+                    "(BASELINE configs[2] shape: 512 MiB of the 4 GiB per GPU), block and stream CRCs verified")
+    else:
+        nunits, unit_bytes = a.units or 16, a.unit_bytes or (16 << 20)
+        workload = (f"{nunits} xz streams of {unit_bytes >> 20} MiB per GPU, 1 MiB LZMA2 blocks + x86 BCJ, "
+                    f"check {a.check} verified (BASELINE configs[3] shape)")
 
     from decompress_amd import _lib
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, min(16, ncpu // max(1, world)))
     t_gen = time.perf_counter()
-    data, units, total_out, total_in, kind, blobs = build_workload(a.format, nunits, unit_bytes, 0x5EED0001 + rank * 1000003, workers)
+    W = build_workload(a.format, nunits, unit_bytes, 0x5EED0001 + rank * 1000003, workers, a.check)
     t_gen = time.perf_counter() - t_gen
+    data, uarr, nun, total_out, total_in, kind, blobs = (W[k] for k in ("data", "uarr", "nunits", "total_out", "total_in", "kind", "blobs"))
 
     # GPU initialisation only after the corpus workers (forked) are gone
     if world > 1:
@@ -129,16 +188,15 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     eng = _lib.Engine(local)
-    uarr = (_lib.Unit * nunits)(*units)
     d_in = eng.dev_alloc(total_in + 64)
     d_units = eng.dev_alloc(C.sizeof(uarr))
-    d_out = eng.dev_alloc(total_out + 64)
-    d_res = eng.dev_alloc(nunits * C.sizeof(_lib.Result))
+    d_out = eng.dev_alloc(W["out_cap"] + 64)
+    d_res = eng.dev_alloc(nun * C.sizeof(_lib.Result))
     eng.upload(d_in, data)
     eng.upload(d_units, bytes(uarr))
 
     def step():
-        eng.decode_batch_device(kind, d_in, total_in, d_units, nunits, d_out, total_out, d_res)
+        eng.decode_batch_device(kind, d_in, total_in, d_units, nun, d_out, W["out_cap"], d_res)
 
     def barrier():
         eng.sync()
@@ -165,41 +223,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # correctness of what was timed: every unit OK, outputs byte-exact on a sample
-    raw = eng.download(d_res, nunits * C.sizeof(_lib.Result))
-    res = (_lib.Result * nunits).from_buffer_copy(raw)
-    bad = [i for i in range(nunits) if res[i].status != 0 or res[i].out_len != unit_bytes]
+    # correctness of what was timed: every unit OK, total size right, outputs byte-exact on a sample
+    raw = eng.download(d_res, nun * C.sizeof(_lib.Result))
+    res = (_lib.Result * nun).from_buffer_copy(raw)
+    bad = [i for i in range(nun) if res[i].status != 0]
     if bad:
         raise SystemExit(f"rank {rank}: {len(bad)} units failed, first {bad[0]} status {res[bad[0]].status}")
-    for i in (0, nunits // 2, nunits - 1):
-        got = eng.download(d_out, unit_bytes, offset=i * unit_bytes)
-        want = zlib.decompress(blobs[i], 47)
+    if sum(r.out_len for r in res) != total_out:
+        raise SystemExit(f"rank {rank}: decoded {sum(r.out_len for r in res)} bytes, expected {total_out}")
+    if a.format in ("gzip", "zlib"):
+        for i in (0, nun // 2, nun - 1):
+            got = eng.download(d_out, unit_bytes, offset=i * unit_bytes)
+            if got != zlib.decompress(blobs[i], 47):
+                raise SystemExit(f"rank {rank}: unit {i} output differs from zlib")
+    else:
+        import bz2
+        import lzma
+        want = (bz2.decompress if a.format == "bzip2" else lzma.decompress)(blobs[-1])
+        got = eng.download(d_out, unit_bytes, offset=res[nun - 1].out_off + res[nun - 1].out_len - unit_bytes)
         if got != want:
-            raise SystemExit(f"rank {rank}: unit {i} output differs from zlib")
+            raise SystemExit(f"rank {rank}: output of the last stream differs from the system decoder")
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = world * total_out / (dt / a.steps) / 1e9
-        kname = "inflate_kernel"
-        kms = [ms for n, ms in spans if n == kname]
-        kavg = sum(kms) / len(kms) if kms else float("nan")
+        names = sorted({k for k, _ in spans})
+        avg = {n: sum(m for k, m in spans if k == n) / max(1, a.steps) for n in names}   # ms per step
+        kname = max(avg, key=avg.get)
+        kavg = avg[kname]
         achieved = (total_in + total_out) / (kavg * 1e-3) / 1e9
         line = {
             "metric": METRIC, "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "format": a.format, "units_per_gpu": nunits, "unit_bytes": unit_bytes,
+            "config": {"workload": workload, "format": a.format, "units_per_gpu": nun, "unit_bytes": unit_bytes,
                        "compressed_bytes_per_gpu": total_in, "decompressed_bytes_per_gpu": total_out,
                        "sharding": f"units by rank x{world}, no collective", "corpus_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": total_in + total_out,
                          "kernel_ms_avg": round(kavg, 4),
-                         "other_kernels_ms_avg": {n: round(sum(m for k, m in spans if k == n) / max(1, len([1 for k, _ in spans if k == n])), 4)
-                                                  for n in sorted({k for k, _ in spans}) if n != kname}},
+                         "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname}},
         }
-        if not a.no_cpu and world >= 1:
-            line["cpu_baseline"] = cpu_baseline(a.format, blobs, unit_bytes)
+        if not a.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(a.format, blobs, W["sample_out"])
         print(json.dumps(line), flush=True)
 
     for p in (d_in, d_units, d_out, d_res):

@@ -1,0 +1,68 @@
+"""GPU: the host-side mirror of the reference's public interface (decompress_amd/api.py):
+same names, same results as example.lisp, same condition types."""
+import io
+
+import pytest
+
+import corpus
+from decompress_amd import api
+
+pytestmark = pytest.mark.gpu
+
+Z = bytes([120, 156, 99, 84, 100, 7, 0, 0, 79, 0, 42])
+GZ2 = bytes([31, 139, 8, 8, 0, 0, 0, 0, 0, 0, 102, 111, 111, 0, 99, 84, 100, 7, 0, 101, 51, 120, 236, 3, 0, 0, 0,
+             31, 139, 8, 8, 0, 0, 0, 0, 0, 0, 98, 97, 114, 0, 99, 84, 100, 7, 0, 101, 51, 120, 236, 3, 0, 0, 0])
+MULTI = bytes([99, 84, 100, 7, 0, 99, 84, 123, 7, 0, 1, 2, 3])
+
+
+def test_example_lisp():
+    # example.lisp:6-7
+    assert api.decompress_all("zlib", Z) == (b"\x01\x21\x07", {"window_size": 32768, "level": 2, "dictionary": None})
+    # example.lisp:12-19
+    out, hdr = api.decompress_all("gzip", GZ2)
+    assert out == b"\x01\x21\x07" * 2 and hdr["filename"] == "foo" and hdr["comment"] is None
+    assert (hdr["textp"], hdr["modification_time"], hdr["extra_flags"], hdr["operating_system"]) == (False, 0, 0, 0)
+    # example.lisp:24-26
+    assert api.decompress_all("deflate", Z, start=2, end=7) == (b"\x01\x21\x07", None)
+    # example.lisp:29-30
+    with pytest.raises(api.DecompressionError, match="Trailing data"):
+        api.decompress_all("zlib", Z + b"\1\2\3")
+    # example.lisp:45-52: decompress leaves trailing data of a stream intact
+    f = io.BytesIO(MULTI)
+    assert api.decompress("deflate", f)[0] == b"\x01\x21\x07"
+    assert api.decompress("deflate", f)[0] == b"\x01\x26\xee"
+    assert f.read() == b"\1\2\3"
+    # example.lisp:58-61
+    s = api.make_decompression_stream("zlib", Z)
+    assert s.read() == b"\x01\x21\x07" and s.header["level"] == 2
+    # example.lisp:67-69
+    with pytest.raises(api.DecompressionError):
+        api.decompress("deflate", MULTI, start=5, all_members_p=True)
+    # example.lisp:72-74
+    out, hdr = api.decompress_all("zlib", bytes([120, 249, 0, 79, 0, 42, 3, 34, 0, 0, 79, 0, 42]),
+                                  dictionary=api.make_simple_zlib_dictionary([bytes([1, 33, 7])]))
+    assert out == b"\x01\x21\x07" and hdr == {"window_size": 32768, "level": 3, "dictionary": 5177386}
+    # example.lisp:77-78 (the formats this engine decodes)
+    assert set(api.list_supported_formats()) <= {"xz", "lzma2", "raw-lzma2", "lzma", "raw-lzma", "bzip2", "gzip", "zlib", "deflate"}
+
+
+def test_conditions():
+    import gzip
+    g = gzip.compress(corpus.text(5000, seed=1))
+    with pytest.raises(api.EOF):
+        api.decompress_all("gzip", g[:-3])
+    with pytest.raises(api.UnrecognizedZlibDictionary) as e:
+        api.decompress_all("zlib", bytes([120, 249, 0, 79, 0, 42, 3, 34, 0, 0, 79, 0, 42]),
+                           dictionary=api.make_simple_zlib_dictionary([b"other"]))
+    assert e.value.checksum == 5177386
+    with pytest.raises(api.DecompressionError, match="dictionary function"):
+        api.decompress_all("zlib", bytes([120, 249, 0, 79, 0, 42, 3, 34, 0, 0, 79, 0, 42]))
+    with pytest.raises(ValueError):
+        api.decompress("brotli", b"")
+    # a stream delivers the good members before raising at the bad one (interface.lisp:105-108)
+    bad = bytearray(g + g); bad[-5] ^= 1
+    s = api.make_full_decompression_stream("gzip", bytes(bad))
+    assert s.read(5000) == corpus.text(5000, seed=1)
+    with pytest.raises(api.DecompressionError):
+        s.read()
+    assert api.adler_32(bytes([1, 33, 7])) == 5177386
