@@ -27,12 +27,26 @@
 namespace {
 
 constexpr uint32_t BZ_STRIDE = 900032;         // per-block scratch stride (bytes / entries)
-constexpr int BZ_ROOT_BITS = 9;
-constexpr int BZ_IN_CHUNK = 1024;              // input staging buffer (one aligned chunk)
-constexpr uint32_t BZ_SEL_STRIDE = 32768;
+constexpr int BZ_ROOT_BITS = 11;              // root table index width; longer codes are resolved from limit[]
+constexpr int BZ_QCAP = 128;                   // LDS symbol queue between the Huffman and the MTF phase
+constexpr int BZ_IN_HALF = 1024;               // input is staged in aligned 1 KiB pieces ...
+constexpr int BZ_IN_RING = 2 * BZ_IN_HALF;     // ... into a two-piece LDS ring
+constexpr int BZ_GROUP = 50;                   // symbols per selector (bzip2.lisp:222-287)
 constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:217-219
 constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
 constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
+
+#ifdef SEMZ_STAMPS
+// diagnostic build only (make STAMPS=1): shader-clock totals of bz_decode_kernel summed over all blocks
+__device__ unsigned long long g_bz_stamps[16];
+#define BZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[4] = {0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
+#define BZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define BZ_COUNT(i) (n_acc[i]++)
+#else
+#define BZ_STAMP_DECL
+#define BZ_STAMP(i) do { } while (0)
+#define BZ_COUNT(i) do { } while (0)
+#endif
 
 struct bz_meta {
     uint32_t n;            // bytes entering the inverse BWT
@@ -82,62 +96,69 @@ __constant__ uint16_t BZ_RAND[512] = {
  645,990,626,197,510,357,358,850,858,364,936,638 };
 
 struct BzTree {
-    uint16_t root[1 << BZ_ROOT_BITS];   // (symbol << 4) | length, 0 = code longer than the root
+    uint16_t root[1 << BZ_ROOT_BITS];   // (symbol << 5) | length, 0 = code longer than the root
     uint16_t sorted[260];
     uint32_t limit[21];                  // (first+count) << (20-len)
-    uint16_t first[21];
+    uint32_t first[21];
     uint16_t offs[21];
     uint32_t maxlen;
 };
 
 struct __align__(16) BzLds {
-    uint8_t inbuf[BZ_IN_CHUNK];
+    uint8_t inbuf[BZ_IN_RING];
+    uint32_t sel4[4096];                 // selectors, 4 bits each (the count field has 15 bits)
     BzTree tree[6];
     uint8_t lens[260];
     uint8_t symbols[256];
     uint16_t count[32];
+    uint16_t symq[BZ_QCAP];              // decoded symbols waiting for the MTF phase (ring)
     int32_t status;
 };
 
 // MSB-first bit reader (msb-bit-reader, bits.lisp:121).  Every lane of the
-// wave holds the same state; the staging buffer is refilled cooperatively
-// (64 lanes x 16 bytes) whenever the reader crosses a chunk boundary.
+// wave holds the same state.  The input is staged cooperatively (64 lanes x 16
+// bytes) in aligned 1 KiB pieces into a 2 KiB LDS ring, so the piece before the
+// one staged last stays readable.
 struct MsbReader {
     const uint8_t *in_v0;   // in_v0 + v = address of v-offset v (see inflate.hip)
-    uint8_t *buf_lds;
+    uint8_t *ring;
     uint64_t in_lo, limit;  // valid v-offsets are [in_lo, limit)
     uint64_t wpos;          // v-offset of the next dword
-    uint64_t s_hi;          // staged chunk is [s_hi - BZ_IN_CHUNK, s_hi)
+    uint64_t s_hi;          // staged: [s_hi - BZ_IN_RING, s_hi) (what lies outside [in_lo, limit) reads as zero)
     uint64_t buf;           // bits left aligned: next bit is bit 63
     int cnt;
     bool near_end;
 
-    __device__ void stage()
+    __device__ __forceinline__ void stage()
     {
-        // all 64 lanes: load the chunk that starts at wpos (1 KiB aligned in v-space)
+        // all 64 lanes: load the piece [s_hi, s_hi + 1 KiB)
         const int lane = threadIdx.x & 63;
-        const uint64_t base = wpos & ~(uint64_t)(BZ_IN_CHUNK - 1);
-        const uint64_t v = base + 16u * lane;
+        const uint64_t v = s_hi + 16u * lane;
         uint4 x = make_uint4(0, 0, 0, 0);
         if (v >= in_lo && v + 16 <= limit) x = *reinterpret_cast<const uint4 *>(in_v0 + v);
         else if (v < limit && v + 16 > in_lo) {
             uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
             for (int b = 0; b < 16; b++) {
                 uint64_t vv = v + b;
-                if (vv >= in_lo && vv < limit) w[b >> 2] |= (uint32_t)in_v0[vv] << (8 * (b & 3));
+                uint32_t byte = (vv >= in_lo && vv < limit) ? in_v0[vv] : 0u;
+                w[0] = (w[0] >> 8) | (w[1] << 24);       // 128-bit shift right by one byte, new byte on top:
+                w[1] = (w[1] >> 8) | (w[2] << 24);       // after 16 steps byte b sits at position b
+                w[2] = (w[2] >> 8) | (w[3] << 24);
+                w[3] = (w[3] >> 8) | (byte << 24);
             }
             x = make_uint4(w[0], w[1], w[2], w[3]);
         }
         lds_sync();
-        *reinterpret_cast<uint4 *>(buf_lds + 16 * lane) = x;
+        *reinterpret_cast<uint4 *>(ring + ((uint32_t)s_hi & (BZ_IN_RING - 1)) + 16 * lane) = x;
         lds_sync();
-        s_hi = base + BZ_IN_CHUNK;
+        s_hi += BZ_IN_HALF;
     }
     __device__ __forceinline__ void refill()
     {
         if (cnt <= 32) {
             if (wpos >= s_hi) stage();
-            uint32_t w = *reinterpret_cast<const uint32_t *>(buf_lds + (wpos & (BZ_IN_CHUNK - 1)));
+            uint32_t w = *reinterpret_cast<const uint32_t *>(ring + ((uint32_t)wpos & (BZ_IN_RING - 1)));
             w = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bswap32(w));
             if (wpos + 4 > limit) near_end = true;
             wpos += 4;
@@ -145,13 +166,13 @@ struct MsbReader {
             cnt += 32;
         }
     }
-    __device__ void init(const uint8_t *v0, uint8_t *lds, uint64_t lo, uint64_t lim, uint64_t v, uint32_t bit_off)
+    __device__ __forceinline__ void init(const uint8_t *v0, uint8_t *lds, uint64_t lo, uint64_t lim, uint64_t v, uint32_t bit_off)
     {
-        in_v0 = v0; buf_lds = lds; in_lo = lo; limit = lim;
-        wpos = v & ~3ull; s_hi = 0; buf = 0; cnt = 0; near_end = false;
+        in_v0 = v0; ring = lds; in_lo = lo; limit = lim;
+        wpos = v & ~3ull; buf = 0; cnt = 0; near_end = false;
         // position of the first bit inside the first dword
         int skip = (int)(v & 3) * 8 + (int)bit_off;
-        s_hi = 0;
+        s_hi = wpos & ~(uint64_t)(BZ_IN_HALF - 1);
         stage();
         refill();
         buf <<= skip;
@@ -188,7 +209,7 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
         for (int l = 1; l <= 20; l++) {
             uint32_t cnt = L.count[l];
             code <<= 1;
-            T.first[l] = (uint16_t)code;
+            T.first[l] = code;
             T.offs[l] = (uint16_t)off;
             code += cnt;
             off += cnt;
@@ -214,7 +235,7 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
         for (int l = 1; l <= BZ_ROOT_BITS; l++) {
             if (v20 < T.limit[l]) {
                 uint32_t idx = T.offs[l] + (v20 >> (20 - l)) - T.first[l];
-                e = (uint16_t)((T.sorted[idx] << 4) | l);
+                e = (uint16_t)((T.sorted[idx] << 5) | l);
                 break;
             }
         }
@@ -225,7 +246,7 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
 }
 
 __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                       bz_meta *meta, uint8_t *pre_all, uint8_t *sel_all)
+                                                       bz_meta *meta, uint8_t *pre_all)
 {
     __shared__ BzLds L;
     const uint32_t u = blockIdx.x;
@@ -233,7 +254,6 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
     const int lane = threadIdx.x & 63;
     const semz_unit un = units[u];
     uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
-    uint8_t *sel = sel_all + (size_t)u * BZ_SEL_STRIDE;
     const uint32_t level = un.param0 >= 1 && un.param0 <= 9 ? un.param0 : 9;
     const uint32_t block_size = level * 100000u;
 
@@ -241,10 +261,13 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
     MsbReader br;
     br.init(in - amis, L.inbuf, amis, un.in_limit + amis, un.in_off + amis, un.in_bit_off);
 
+    BZ_STAMP_DECL
     int status = SEMZ_OK;
     uint32_t detail = 0;
     bool eof = false;
     uint32_t n = 0, orig = 0, randomized = 0, want_crc = 0;
+    uint64_t P = 0;                 // bit position (v-space) once the symbol loop has taken over from `br`
+    bool in_symbols = false;
 #define BZ_FAIL(code, det) do { status = (code); detail = (det); goto done; } while (0)
 #define BZ_EOFCHK() do { if (eof) BZ_FAIL(SEMZ_EOF, 0); } while (0)
     {
@@ -277,6 +300,7 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
         // read-bzip2-selectors (bzip2.lisp:302-311): codes 0,10,110,1110,11110,111110,111111, then MTF
         {
             uint32_t stack = 0x543210u;                 // nibble j = tree at MTF position j
+            uint32_t packed = 0;                        // eight selectors per LDS word
             for (uint32_t i = 0; i < nsel; i++) {
                 br.refill();
                 if (br.short_of(6)) BZ_FAIL(SEMZ_EOF, 0);
@@ -289,9 +313,12 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
                 uint32_t low = stack & ((1u << (4 * idx)) - 1);
                 uint32_t high = idx >= 7 ? 0 : (stack >> (4 * (idx + 1))) << (4 * (idx + 1));
                 stack = high | (low << 4) | val;
-                if (lane == 0) sel[i] = (uint8_t)val;
+                packed |= val << (4 * (i & 7));
+                if ((i & 7) == 7 || i + 1 == nsel) {
+                    if (lane == 0) L.sel4[i >> 3] = packed;
+                    packed = 0;
+                }
             }
-            __threadfence_block();                      // sel[] is read back from memory below
         }
         // read-bzip2-trees (bzip2.lisp:317-343): 5-bit start, then 0 = emit, 10 = +1, 11 = -1
         for (uint32_t t = 0; t < ntrees; t++) {
@@ -309,90 +336,254 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
                 if (lane == 0) L.lens[i] = (uint8_t)cur;
             }
             lds_sync();
-            int ts = bz_build_tree(L, L.tree[t], (int)nsym + 2);
+            // a call result counts as divergent: say that it is uniform, or every value after this loop lands in VGPRs
+            int ts = __builtin_amdgcn_readfirstlane(bz_build_tree(L, L.tree[t], (int)nsym + 2));
             if (ts != SEMZ_OK) BZ_FAIL(ts, 0);
         }
         if (nsym == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 1);
         lds_sync();
 
-        // inverse-MTF stack: lane i holds entries 4i .. 4i+3 (byte j of the word = entry 4i+j)
-        uint32_t w = 0;
-        for (int j = 0; j < 4; j++) {
-            uint32_t k = 4 * lane + j;
-            if (k < nsym) w |= (uint32_t)L.symbols[k] << (8 * j);
-        }
+        // inverse-MTF list: lane i of mtf_a holds entry i < 64; entries 64 .. 255 stay in L.symbols
+        uint32_t mtf_a = L.symbols[lane];
 
-        // decode-bzip2-huffman+rle2 fused with decode-bzip2-mtf-in-place
+        // decode-bzip2-huffman+rle2 and decode-bzip2-mtf-in-place, in two phases that alternate inside the
+        // wave (a lone wave issues one instruction every ~5 clocks whatever its kind, so the work is organised
+        // to spend as few instructions per symbol as possible):
+        //
+        // Phase 1, Huffman.  Lane l looks up the code that would start at bit P + l, so one pair of LDS round
+        // trips (input window, root table) serves every symbol that starts inside the next 64 bits.  The wave
+        // follows the chain off -> off + len(off) with readlane and collects the start positions in a 64-bit
+        // mask; group boundary (50 symbols per selector) and end-of-block are applied to the mask afterwards,
+        // and the surviving lanes append their symbols to an LDS queue in order (rank = mbcnt of the mask).
+        //
+        // Phase 2, RLE2 + MTF, 64 queued symbols at a time.  Every symbol is RUNA/RUNB or an MTF index, so the
+        // run symbols between two MTF symbols are one run whose bits come straight out of the RUNB ballot; only
+        // MTF symbols are walked one by one.  The first 64 entries of the MTF list live in one VGPR (one entry
+        // per lane): an index below 64 (nearly all of them) is a readlane, a DPP wave shift and a select; the
+        // other entries stay in LDS and are moved there.  The bytes of consecutive MTF symbols collect in one
+        // VGPR (lane e = e-th of them) and are stored together in front of the next run or at the end of the
+        // batch; a run is stored by all lanes at once (nothing in this kernel reads `pre` back).
+        //
+        // A failure seen by phase 1 waits until phase 2 has drained the queue: the first failure in stream
+        // order is the one the reference signals.
         const uint32_t eob = nsym + 1;
+        const uint64_t endbits = 8 * br.limit;
+        const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(L.inbuf);
         uint32_t ab_len = 0, ab_val = 0;
-        bool finished = false;
-        for (uint32_t g = 0; !finished; g++) {
-            if (g >= nsel) BZ_FAIL(SEMZ_E_BZ_SELECTORS_EXHAUSTED, 0);
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel[g]);
-            const BzTree &T = L.tree[t];
-            const int maxlen = (int)T.maxlen;
-            for (int k = 0; k < 50; k++) {
-                br.refill();
-                uint32_t e = T.root[br.peek(BZ_ROOT_BITS)];
-                e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
-                uint32_t len = e & 15, sym = e >> 4;
-                if (len == 0) {
-                    uint32_t v20 = br.peek(20);
+        uint32_t qhead = 0, qn = 0;                 // symbol queue: L.symq[(qhead + i) % BZ_QCAP], i < qn
+        int pend = SEMZ_OK;                         // phase-1 failure waiting for the queue to drain
+        uint32_t pend_detail = 0;
+        bool finished = false;                      // end-of-block symbol seen
+        uint32_t g = 0, k = BZ_GROUP, t = 0, maxlen = 0;
+        P = br.bitpos();
+        in_symbols = true;
+        BZ_STAMP(0);
+
+        auto emit_run = [&](uint32_t front, uint32_t run) {
+            BZ_COUNT(4);
+            for (uint32_t k2 = lane; k2 < run; k2 += 64) pre[n + k2] = (uint8_t)front;
+            n += run;
+        };
+
+        for (;;) {
+            // ---- phase 1: one window ----
+            BZ_STAMP(2);
+            if (!finished && pend == SEMZ_OK && qn <= (uint32_t)BZ_QCAP - 64) {
+                if (k == (uint32_t)BZ_GROUP) {
+                    if (g >= nsel) { pend = SEMZ_E_BZ_SELECTORS_EXHAUSTED; continue; }
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)((L.sel4[g >> 3] >> (4 * (g & 7))) & 15));
+                    maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tree[t].maxlen);
+                    g++;
+                    k = 0;
+                }
+                const BzTree &T = L.tree[t];
+                while ((P >> 3) + 16 > br.s_hi) { br.stage(); BZ_COUNT(3); }
+                BZ_COUNT(0);
+                const uint64_t bp = P + (uint32_t)lane;
+                const uint32_t d = (uint32_t)(bp >> 5);
+                const uint32_t hi = __builtin_bswap32(ring32[d & (BZ_IN_RING / 4 - 1)]);
+                const uint32_t lo = __builtin_bswap32(ring32[(d + 1) & (BZ_IN_RING / 4 - 1)]);
+                const uint32_t top = (uint32_t)(((((uint64_t)hi << 32) | lo) << ((uint32_t)bp & 31)) >> 32);
+                uint32_t ev = T.root[top >> (32 - BZ_ROOT_BITS)];
+                if (__builtin_amdgcn_ballot_w64((ev & 31) == 0)) {
+                    // codes longer than the root index: every such lane searches the limits (rare)
+                    BZ_COUNT(2);
+                    const uint32_t v20 = top >> 12;
                     for (int l = BZ_ROOT_BITS + 1; l <= 20; l++) {
-                        if (v20 < T.limit[l]) {
-                            sym = T.sorted[T.offs[l] + (v20 >> (20 - l)) - T.first[l]];
-                            len = l;
-                            break;
-                        }
+                        const uint32_t lim = T.limit[l], first = T.first[l], offs = T.offs[l];
+                        if ((ev & 31) == 0 && v20 < lim) ev = ((uint32_t)T.sorted[offs + (v20 >> (20 - l)) - first] << 5) | (uint32_t)l;
                     }
-                    sym = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym);
-                    len = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
                 }
-                if (br.short_of(maxlen)) BZ_FAIL(SEMZ_EOF, 0);      // trees are always full-read (80 trailing bits)
-                br.drop(len);
-                if (sym < 2) {
-                    if (ab_len >= (uint32_t)BZ_AB_BOUND) BZ_FAIL(SEMZ_E_BZ_AB_RUN_LENGTH, 0);
-                    ab_val |= sym << ab_len;
-                    ab_len++;
-                    continue;
+                // the chain of symbol starts inside this window
+                uint64_t mask = 0;
+                uint32_t off = 0;
+                bool short_input = false;
+                if (endbits - P >= 64 + 20) {
+                    do {
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)off) & 31;
+                        mask |= 1ull << off;
+                        off += len;
+                    } while (off < 64);
+                } else {
+                    // the last bits of the input: the reference runs out of data when fewer bits than the
+                    // longest code of the tree are left (trees are always full-read, huffman.lisp)
+                    do {
+                        if (endbits - (P + off) < maxlen) { short_input = true; break; }
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)off) & 31;
+                        mask |= 1ull << off;
+                        off += len;
+                    } while (off < 64);
                 }
-                if (ab_len) {
-                    uint32_t run = (ab_val | (1u << ab_len)) - 1;
-                    if (n + run > block_size) BZ_FAIL(SEMZ_E_BZ_AB_RUN_SIZE, 0);
-                    uint8_t front = (uint8_t)__builtin_amdgcn_readfirstlane((int)(w & 0xFF));
-                    for (uint32_t i = lane; i < run; i += 64) pre[n + i] = front;
-                    n += run;
+                // group boundary: symbols past it were looked up in the wrong tree
+                uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
+                if (cnt > (uint32_t)BZ_GROUP - k) {
+                    uint64_t rest = mask;
+                    for (uint32_t i = (uint32_t)BZ_GROUP - k; i; i--) rest &= rest - 1;
+                    off = (uint32_t)__builtin_ctzll(rest);
+                    mask &= (1ull << off) - 1;
+                    cnt = (uint32_t)BZ_GROUP - k;
+                    short_input = false;
+                }
+                // end of block
+                const bool start = (mask >> lane) & 1;
+                const uint64_t eobm = __builtin_amdgcn_ballot_w64(start && (ev >> 5) == eob);
+                uint64_t qmask = mask;
+                if (eobm) {
+                    const uint32_t e = (uint32_t)__builtin_ctzll(eobm);
+                    qmask = mask & ((1ull << e) - 1);
+                    off = e + ((uint32_t)__builtin_amdgcn_readlane((int)ev, (int)e) & 31);
+                    finished = true;
+                    short_input = false;
+                }
+                if (short_input) pend = SEMZ_EOF;
+                // append the symbols to the queue in order
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(qmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qmask, 0));
+                if ((qmask >> lane) & 1) L.symq[(qhead + qn + rank) & (BZ_QCAP - 1)] = (uint16_t)(ev >> 5);
+                qn += (uint32_t)__builtin_popcountll(qmask);
+                k += cnt;
+                P += off;
+#ifdef SEMZ_STAMPS
+                n_acc[1] += cnt;
+#endif
+                if (!finished && pend == SEMZ_OK && qn < 64) { BZ_STAMP(1); continue; }
+            }
+            // ---- phase 2: up to 64 queued symbols ----
+            BZ_STAMP(1);
+            const bool last = finished || pend != SEMZ_OK;
+            const uint32_t m = qn < 64 ? qn : 64;
+            lds_sync();
+            const uint32_t sq = (uint32_t)lane < m ? L.symq[(qhead + lane) & (BZ_QCAP - 1)] : 0u;
+            lds_sync();
+            qhead = (qhead + m) & (BZ_QCAP - 1);
+            qn -= m;
+            const bool valid = (uint32_t)lane < m;
+            const uint64_t bmask = __builtin_amdgcn_ballot_w64(valid && sq == 1);
+            uint64_t mtfmask = __builtin_amdgcn_ballot_w64(valid && sq >= 2);
+            // MTF symbols with run symbols (or a pending run) right below them
+            const uint64_t runmask = __builtin_amdgcn_ballot_w64(valid && sq < 2);
+            uint64_t afterrun = mtfmask & (runmask << 1);
+            if (ab_len) afterrun |= mtfmask & (0 - mtfmask);
+            int err = SEMZ_OK;                       // a failure leaves the walk through the loop condition
+            uint32_t c = 0, outv = 0;                // lane e < c of outv holds the byte of the e-th MTF symbol since the last store
+            // lane 0 takes `c0`, lane l > 0 takes lane l - 1 (the DPP shift leaves `old` in lane 0)
+            auto shr1 = [](uint32_t v, uint32_t c0) {
+                return (uint32_t)__builtin_amdgcn_update_dpp((int)c0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            };
+            auto move_to_front = [&](uint32_t x, uint32_t idx) {
+                const uint32_t sh = shr1(mtf_a, x);
+                mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
+                outv = (uint32_t)lane == c ? x : outv;
+                c++;
+            };
+            // stores the pending MTF bytes; an MTF symbol that arrives with the block full is the reference's failure
+            auto store_pending = [&]() {
+                if (n + c > block_size) { if (err == SEMZ_OK) err = SEMZ_E_BZ_TOO_MANY_CODES; mtfmask = 0; }
+                else if ((uint32_t)lane < c) pre[n + lane] = (uint8_t)outv;
+                n += c;
+                c = 0;
+            };
+            while (mtfmask) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(mtfmask);
+                mtfmask &= ~(1ull << i);
+                if ((afterrun >> i) & 1) {
+                    store_pending();
+                    // the run symbols [lastpos, i) sit between the MTF symbol before and this one
+                    const uint64_t below = ~runmask & ((1ull << i) - 1);
+                    const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
+                    const uint32_t rl = i - lastpos;
+                    ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
+                    ab_len += rl;
+                    const uint32_t run = (ab_val | (1u << (ab_len & 31))) - 1;
+                    if (err != SEMZ_OK) { }
+                    else if (ab_len > (uint32_t)BZ_AB_BOUND) { err = SEMZ_E_BZ_AB_RUN_LENGTH; mtfmask = 0; }
+                    else if (n + run > block_size) { err = SEMZ_E_BZ_AB_RUN_SIZE; mtfmask = 0; }
+                    else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
                     ab_len = 0;
                     ab_val = 0;
                 }
-                if (sym == eob) { finished = true; break; }
-                if (n >= block_size) BZ_FAIL(SEMZ_E_BZ_TOO_MANY_CODES, 0);
-                // move-to-front of entry idx
-                uint32_t idx = sym - 1, q = idx >> 2, r = idx & 3;
-                uint32_t wq = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)q);
-                uint32_t x = (wq >> (8 * r)) & 0xFF;
-                if (idx) {
-                    uint32_t prev = (uint32_t)__shfl_up((int)w, 1, 64);
-                    uint32_t shifted = (w << 8) | (lane == 0 ? x : prev >> 24);
-                    if ((uint32_t)lane < q) w = shifted;
-                    else if ((uint32_t)lane == q) {
-                        uint32_t mask = r == 3 ? 0xFFFFFFFFu : (1u << (8 * (r + 1))) - 1;
-                        w = (shifted & mask) | (w & ~mask);
+                // move-to-front of entry idx >= 1 (after a failure this still runs once, harmlessly)
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)sq, (int)i) - 1;
+                if (idx < 64) {
+                    move_to_front((uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx), idx);
+                } else {
+                    // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx]);
+                    uint32_t v[3];
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        const uint32_t p = 64 + 64 * c3 + lane;
+                        v[c3] = p < idx ? L.symbols[p] : 0u;
                     }
+                    lds_sync();
+                    for (int c3 = 0; c3 < 3; c3++) {
+                        const uint32_t p = 64 + 64 * c3 + lane;
+                        if (p < idx) L.symbols[p + 1] = (uint8_t)v[c3];
+                    }
+                    if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
+                    lds_sync();
+                    move_to_front(x, idx);
                 }
-                if (lane == 0) pre[n] = (uint8_t)x;
-                n++;
+            }
+            store_pending();
+            if (err != SEMZ_OK) BZ_FAIL(err, 0);
+            {
+                // run symbols at the end of the batch stay pending
+                const uint64_t below = ~runmask & (m == 64 ? ~0ull : (1ull << m) - 1);
+                const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
+                const uint32_t rl = m - lastpos;
+                if (rl) {
+                    if (ab_len + rl > (uint32_t)BZ_AB_BOUND) BZ_FAIL(SEMZ_E_BZ_AB_RUN_LENGTH, 0);
+                    ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
+                    ab_len += rl;
+                }
+            }
+            if (last && qn == 0) {
+                if (pend != SEMZ_OK) BZ_FAIL(pend, pend_detail);
+                if (ab_len) {                        // the run in front of the end-of-block symbol
+                    const uint32_t run = (ab_val | (1u << ab_len)) - 1;
+                    if (n + run > block_size) BZ_FAIL(SEMZ_E_BZ_AB_RUN_SIZE, 0);
+                    emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
+                }
+                break;
             }
         }
+        BZ_STAMP(2);
         // decode-bzip2-bwt's precondition; deliberate divergence, see DESIGN.md
         if (n == 0 ? orig >= block_size : orig >= n) BZ_FAIL(SEMZ_E_BZ_ORIGPTR, orig);
     }
 done:
+#ifdef SEMZ_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 4; i++) atomicAdd(&g_bz_stamps[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 6; i++) atomicAdd(&g_bz_stamps[4 + i], (unsigned long long)n_acc[i]);
+        atomicAdd(&g_bz_stamps[10], 1ull);
+        atomicAdd(&g_bz_stamps[11], (unsigned long long)n);
+    }
+#endif
     if (lane == 0) {
         bz_meta m;
         m.n = n; m.orig = orig; m.randomized = randomized; m.want_crc = want_crc;
         m.status = status; m.detail = detail;
-        m.end_bit = br.bitpos() - 8 * amis;
+        m.end_bit = (in_symbols ? P : br.bitpos()) - 8 * amis;
         m.out_len = 0; m.out_off = 0;
         meta[u] = m;
     }
@@ -692,18 +883,29 @@ __global__ __launch_bounds__(1024) void bz_rle1_kernel(uint32_t nunits, const bz
 
 } // namespace
 
+#ifdef SEMZ_STAMPS
+extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bz_stamps), sizeof(g_bz_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bz_stamps), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
 {
     (void)in_len;
-    void *meta, *pre, *post, *tt, *sel, *segs;
+    void *meta, *pre, *post, *tt, *segs;
     int rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_META, (size_t)nunits * sizeof(bz_meta), &meta))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_DATA, (size_t)nunits * BZ_STRIDE * 2, &pre))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_TT, (size_t)nunits * BZ_STRIDE * sizeof(uint32_t), &tt))) return rc;
-    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * (BZ_SEL_STRIDE + BZ_SEGS * sizeof(bz_seg)), &sel))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * BZ_SEGS * sizeof(bz_seg), &segs))) return rc;
     post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
-    segs = (uint8_t *)sel + (size_t)nunits * BZ_SEL_STRIDE;
     const size_t smem = (3 * (BZ_CHAINS + 1) + 16) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
@@ -712,7 +914,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
         attr_set = true;
     }
     semz_span_begin(c, "bz_decode_kernel");
-    bz_decode_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)sel);
+    bz_decode_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre);
     semz_span_end(c);
     semz_span_begin(c, "bz_bwt_kernel");
     bz_bwt_kernel<<<nunits, 1024, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,

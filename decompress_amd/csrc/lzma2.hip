@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
             if (lane < n) ob[lane] = L.ring[(lane + shift) & LZ_MASK];
             flushed = n;
         }
+        flushed = uni(flushed);         // see the note at the end
         if (flushed || !head) {
             while (p - flushed >= (uint64_t)LZ_FLUSH) {
                 const uint64_t a = flushed + 16u * lane;
@@ -253,6 +254,9 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                 flushed = p;
             }
         }
+        // the optimiser threads the lane-masked head store into the update of `flushed`, which then counts as
+        // divergent and drags the whole decoder state into VGPRs; this pins it as the wave-uniform value it is
+        flushed = uni(flushed);
     };
     // byte of history at position s < p: the ring holds [p - (LZ_RING - MAX_MATCH - LZ_FLUSH) .. p) at least
     auto history_byte = [&](uint64_t s) -> uint32_t {
