@@ -28,7 +28,7 @@ namespace {
 
 constexpr uint32_t BZ_STRIDE = 900032;         // per-block scratch stride (bytes / entries)
 constexpr int BZ_ROOT_BITS = 11;              // root table index width; longer codes are resolved from limit[]
-constexpr int BZ_QCAP = 128;                   // LDS symbol queue between the Huffman and the MTF phase
+constexpr int BZ_QCAP = 1024;                  // LDS symbol queue between the Huffman wave and the MTF wave
 constexpr int BZ_IN_HALF = 1024;               // input is staged in aligned 1 KiB pieces ...
 constexpr int BZ_IN_RING = 2 * BZ_IN_HALF;     // ... into a two-piece LDS ring
 constexpr int BZ_GROUP = 50;                   // symbols per selector (bzip2.lisp:222-287)
@@ -39,7 +39,7 @@ constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per
 #ifdef SEMZ_STAMPS
 // diagnostic build only (make STAMPS=1): shader-clock totals of bz_decode_kernel summed over all blocks
 __device__ unsigned long long g_bz_stamps[16];
-#define BZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[4] = {0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
+#define BZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
 #define BZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define BZ_COUNT(i) (n_acc[i]++)
 #else
@@ -104,6 +104,16 @@ struct BzTree {
     uint32_t maxlen;
 };
 
+struct BzShare {           // producer/consumer hand-over (LDS, workgroup-scope atomics on the flags)
+    uint32_t produced;     // symbols appended to symq so far (producer)
+    uint32_t consumed;     // symbols taken out of it (consumer)
+    uint32_t done;         // the producer has ended: status .. end_hi are final
+    uint32_t abort;        // the consumer has failed: the producer may stop
+    uint32_t hdr_ready;    // header parsed: L.symbols holds the MTF alphabet
+    int32_t status;
+    uint32_t detail, orig, randomized, want_crc, end_lo, end_hi;
+};
+
 struct __align__(16) BzLds {
     uint8_t inbuf[BZ_IN_RING];
     uint32_t sel4[4096];                 // selectors, 4 bits each (the count field has 15 bits)
@@ -111,8 +121,9 @@ struct __align__(16) BzLds {
     uint8_t lens[260];
     uint8_t symbols[256];
     uint16_t count[32];
-    uint16_t symq[BZ_QCAP];              // decoded symbols waiting for the MTF phase (ring)
+    uint16_t symq[BZ_QCAP];              // decoded symbols waiting for the MTF wave (ring)
     int32_t status;
+    BzShare sh;
 };
 
 // MSB-first bit reader (msb-bit-reader, bits.lisp:121).  Every lane of the
@@ -245,152 +256,156 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
     return SEMZ_OK;
 }
 
-__global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                       bz_meta *meta, uint8_t *pre_all)
+__global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
+                                                        bz_meta *meta, uint8_t *pre_all)
 {
+    // Two waves per block, a producer and a consumer, joined by a symbol queue in LDS.  A lone wave issues one
+    // instruction every ~5 clocks whatever its kind and a bzip2 batch has fewer blocks than the chip has SIMDs,
+    // so the two halves of the work run side by side and each is organised to spend few instructions per symbol.
+    //
+    // Wave 0: header, selectors, trees, then Huffman.  Lane l looks up the code that would start at bit P + l,
+    // so one pair of LDS round trips (input window, root table) serves every symbol that starts inside the next
+    // 64 bits.  The wave follows the chain off -> off + len(off) with readlane and collects the start positions
+    // in a 64-bit mask; group boundary (50 symbols per selector) and end-of-block are applied to the mask
+    // afterwards, and the surviving lanes append their symbols to the queue in order (rank = mbcnt of the mask).
+    //
+    // Wave 1: RLE2 + MTF, 64 queued symbols at a time.  Every symbol is RUNA/RUNB or an MTF index, so the run
+    // symbols between two MTF symbols are one run whose bits come straight out of the RUNB ballot; only MTF
+    // symbols are walked one by one.  The first 64 entries of the MTF list live in one VGPR (one entry per
+    // lane): an index below 64 (nearly all of them) is a readlane, a DPP wave shift and a select; the other
+    // entries stay in LDS and are moved there.  The bytes of consecutive MTF symbols collect in one VGPR (lane
+    // e = e-th of them) and are stored together in front of the next run or at the end of the batch; a run is
+    // stored by all lanes at once (nothing in this kernel reads `pre` back).
+    //
+    // Failures: the consumer's own failure comes first in stream order and wins; a failure of the producer is
+    // reported once the consumer has drained the queue.  Both waves always reach their end: the producer sets
+    // `done` on every path and leaves its wait loop when the consumer sets `abort`; the consumer only waits for
+    // symbols or `done`.
     __shared__ BzLds L;
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
     const int lane = threadIdx.x & 63;
+    const uint32_t wid = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < sizeof(BzShare) / 4) reinterpret_cast<uint32_t *>(&L.sh)[threadIdx.x] = 0;
+    __syncthreads();
     const semz_unit un = units[u];
     uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
     const uint32_t level = un.param0 >= 1 && un.param0 <= 9 ? un.param0 : 9;
     const uint32_t block_size = level * 100000u;
-
     const uint64_t amis = (uint64_t)((uintptr_t)in & 15);
-    MsbReader br;
-    br.init(in - amis, L.inbuf, amis, un.in_limit + amis, un.in_off + amis, un.in_bit_off);
-
     BZ_STAMP_DECL
-    int status = SEMZ_OK;
-    uint32_t detail = 0;
-    bool eof = false;
-    uint32_t n = 0, orig = 0, randomized = 0, want_crc = 0;
-    uint64_t P = 0;                 // bit position (v-space) once the symbol loop has taken over from `br`
-    bool in_symbols = false;
+#define BZ_LD(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&(x), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)))
+#define BZ_ST(x, v) __hip_atomic_store(&(x), (uint32_t)(v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+    if (wid == 0) {
+        // ================= producer =================
+        MsbReader br;
+        br.init(in - amis, L.inbuf, amis, un.in_limit + amis, un.in_off + amis, un.in_bit_off);
+        int status = SEMZ_OK;
+        uint32_t detail = 0;
+        bool eof = false;
+        uint32_t orig = 0, randomized = 0, want_crc = 0;
+        uint64_t P = 0;                 // bit position (v-space) once the symbol loop has taken over from `br`
+        bool in_symbols = false;
 #define BZ_FAIL(code, det) do { status = (code); detail = (det); goto done; } while (0)
 #define BZ_EOFCHK() do { if (eof) BZ_FAIL(SEMZ_EOF, 0); } while (0)
-    {
-        // 48-bit block magic (bzip2.lisp:460-463)
-        uint32_t m1 = br.read(24, eof); BZ_EOFCHK();
-        uint32_t m2 = br.read(24, eof); BZ_EOFCHK();
-        if (m1 != 0x314159u || m2 != 0x265359u) BZ_FAIL(SEMZ_E_BZ_BLOCK_MAGIC, 0);
-        // parse-bzip2-block-header, bzip2.lisp:351-395
-        uint32_t c1 = br.read(16, eof); BZ_EOFCHK();
-        uint32_t c2 = br.read(16, eof); BZ_EOFCHK();
-        want_crc = (c1 << 16) | c2;
-        randomized = br.read(1, eof); BZ_EOFCHK();
-        orig = br.read(24, eof); BZ_EOFCHK();
-        uint32_t l1 = br.read(16, eof); BZ_EOFCHK();
-        if (l1 == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 0);
-        uint32_t nsym = 0;
-        for (int i = 0; i < 16; i++) {
-            if (!((l1 >> (15 - i)) & 1)) continue;
-            uint32_t l2 = br.read(16, eof); BZ_EOFCHK();
-            for (int j = 0; j < 16; j++)
-                if ((l2 >> (15 - j)) & 1) {
-                    if (lane == 0) L.symbols[nsym] = (uint8_t)(16 * i + j);
-                    nsym++;
-                }
-        }
-        uint32_t ntrees = br.read(3, eof); BZ_EOFCHK();
-        uint32_t nsel = br.read(15, eof); BZ_EOFCHK();
-        if (ntrees < 2 || ntrees > 6) BZ_FAIL(SEMZ_E_BZ_TREE_COUNT, ntrees);
-        if (nsel == 0) BZ_FAIL(SEMZ_E_BZ_NO_SELECTORS, 0);
-        // read-bzip2-selectors (bzip2.lisp:302-311): codes 0,10,110,1110,11110,111110,111111, then MTF
         {
-            uint32_t stack = 0x543210u;                 // nibble j = tree at MTF position j
-            uint32_t packed = 0;                        // eight selectors per LDS word
-            for (uint32_t i = 0; i < nsel; i++) {
-                br.refill();
-                if (br.short_of(6)) BZ_FAIL(SEMZ_EOF, 0);
-                uint32_t six = br.peek(6);
-                uint32_t idx = (uint32_t)__builtin_clz(~(six << 26));   // leading ones
-                if (idx > 6) idx = 6;
-                br.drop(idx < 6 ? idx + 1 : 6);
-                if (idx >= ntrees) BZ_FAIL(SEMZ_E_BZ_SELECTOR, idx);
-                uint32_t val = (stack >> (4 * idx)) & 15;
-                uint32_t low = stack & ((1u << (4 * idx)) - 1);
-                uint32_t high = idx >= 7 ? 0 : (stack >> (4 * (idx + 1))) << (4 * (idx + 1));
-                stack = high | (low << 4) | val;
-                packed |= val << (4 * (i & 7));
-                if ((i & 7) == 7 || i + 1 == nsel) {
-                    if (lane == 0) L.sel4[i >> 3] = packed;
-                    packed = 0;
-                }
+            // 48-bit block magic (bzip2.lisp:460-463)
+            uint32_t m1 = br.read(24, eof); BZ_EOFCHK();
+            uint32_t m2 = br.read(24, eof); BZ_EOFCHK();
+            if (m1 != 0x314159u || m2 != 0x265359u) BZ_FAIL(SEMZ_E_BZ_BLOCK_MAGIC, 0);
+            // parse-bzip2-block-header, bzip2.lisp:351-395
+            uint32_t c1 = br.read(16, eof); BZ_EOFCHK();
+            uint32_t c2 = br.read(16, eof); BZ_EOFCHK();
+            want_crc = (c1 << 16) | c2;
+            randomized = br.read(1, eof); BZ_EOFCHK();
+            orig = br.read(24, eof); BZ_EOFCHK();
+            uint32_t l1 = br.read(16, eof); BZ_EOFCHK();
+            if (l1 == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 0);
+            uint32_t nsym = 0;
+            for (int i = 0; i < 16; i++) {
+                if (!((l1 >> (15 - i)) & 1)) continue;
+                uint32_t l2 = br.read(16, eof); BZ_EOFCHK();
+                for (int j = 0; j < 16; j++)
+                    if ((l2 >> (15 - j)) & 1) {
+                        if (lane == 0) L.symbols[nsym] = (uint8_t)(16 * i + j);
+                        nsym++;
+                    }
             }
-        }
-        // read-bzip2-trees (bzip2.lisp:317-343): 5-bit start, then 0 = emit, 10 = +1, 11 = -1
-        for (uint32_t t = 0; t < ntrees; t++) {
-            int cur = (int)br.read(5, eof); BZ_EOFCHK();
-            for (uint32_t i = 0; i < nsym + 2; i++) {
-                for (;;) {
-                    if (cur < 1 || cur > 20) BZ_FAIL(SEMZ_E_BZ_CODELEN, 0);
+            uint32_t ntrees = br.read(3, eof); BZ_EOFCHK();
+            uint32_t nsel = br.read(15, eof); BZ_EOFCHK();
+            if (ntrees < 2 || ntrees > 6) BZ_FAIL(SEMZ_E_BZ_TREE_COUNT, ntrees);
+            if (nsel == 0) BZ_FAIL(SEMZ_E_BZ_NO_SELECTORS, 0);
+            // read-bzip2-selectors (bzip2.lisp:302-311): codes 0,10,110,1110,11110,111110,111111, then MTF
+            {
+                uint32_t stack = 0x543210u;                 // nibble j = tree at MTF position j
+                uint32_t packed = 0;                        // eight selectors per LDS word
+                for (uint32_t i = 0; i < nsel; i++) {
                     br.refill();
-                    if (br.short_of(2)) BZ_FAIL(SEMZ_EOF, 0);
-                    uint32_t two = br.peek(2);
-                    if (two < 2) { br.drop(1); break; }
-                    br.drop(2);
-                    cur += two == 2 ? 1 : -1;
+                    if (br.short_of(6)) BZ_FAIL(SEMZ_EOF, 0);
+                    uint32_t six = br.peek(6);
+                    uint32_t idx = (uint32_t)__builtin_clz(~(six << 26));   // leading ones
+                    if (idx > 6) idx = 6;
+                    br.drop(idx < 6 ? idx + 1 : 6);
+                    if (idx >= ntrees) BZ_FAIL(SEMZ_E_BZ_SELECTOR, idx);
+                    uint32_t val = (stack >> (4 * idx)) & 15;
+                    uint32_t low = stack & ((1u << (4 * idx)) - 1);
+                    uint32_t high = idx >= 7 ? 0 : (stack >> (4 * (idx + 1))) << (4 * (idx + 1));
+                    stack = high | (low << 4) | val;
+                    packed |= val << (4 * (i & 7));
+                    if ((i & 7) == 7 || i + 1 == nsel) {
+                        if (lane == 0) L.sel4[i >> 3] = packed;
+                        packed = 0;
+                    }
                 }
-                if (lane == 0) L.lens[i] = (uint8_t)cur;
             }
+            // read-bzip2-trees (bzip2.lisp:317-343): 5-bit start, then 0 = emit, 10 = +1, 11 = -1
+            for (uint32_t t = 0; t < ntrees; t++) {
+                int cur = (int)br.read(5, eof); BZ_EOFCHK();
+                for (uint32_t i = 0; i < nsym + 2; i++) {
+                    for (;;) {
+                        if (cur < 1 || cur > 20) BZ_FAIL(SEMZ_E_BZ_CODELEN, 0);
+                        br.refill();
+                        if (br.short_of(2)) BZ_FAIL(SEMZ_EOF, 0);
+                        uint32_t two = br.peek(2);
+                        if (two < 2) { br.drop(1); break; }
+                        br.drop(2);
+                        cur += two == 2 ? 1 : -1;
+                    }
+                    if (lane == 0) L.lens[i] = (uint8_t)cur;
+                }
+                lds_sync();
+                // a call result counts as divergent: say that it is uniform, or every value after this loop lands in VGPRs
+                int ts = __builtin_amdgcn_readfirstlane(bz_build_tree(L, L.tree[t], (int)nsym + 2));
+                if (ts != SEMZ_OK) BZ_FAIL(ts, 0);
+            }
+            if (nsym == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 1);
             lds_sync();
-            // a call result counts as divergent: say that it is uniform, or every value after this loop lands in VGPRs
-            int ts = __builtin_amdgcn_readfirstlane(bz_build_tree(L, L.tree[t], (int)nsym + 2));
-            if (ts != SEMZ_OK) BZ_FAIL(ts, 0);
-        }
-        if (nsym == 0) BZ_FAIL(SEMZ_E_BZ_NO_SYMBOLS, 1);
-        lds_sync();
+            BZ_ST(L.sh.hdr_ready, 1);
 
-        // inverse-MTF list: lane i of mtf_a holds entry i < 64; entries 64 .. 255 stay in L.symbols
-        uint32_t mtf_a = L.symbols[lane];
-
-        // decode-bzip2-huffman+rle2 and decode-bzip2-mtf-in-place, in two phases that alternate inside the
-        // wave (a lone wave issues one instruction every ~5 clocks whatever its kind, so the work is organised
-        // to spend as few instructions per symbol as possible):
-        //
-        // Phase 1, Huffman.  Lane l looks up the code that would start at bit P + l, so one pair of LDS round
-        // trips (input window, root table) serves every symbol that starts inside the next 64 bits.  The wave
-        // follows the chain off -> off + len(off) with readlane and collects the start positions in a 64-bit
-        // mask; group boundary (50 symbols per selector) and end-of-block are applied to the mask afterwards,
-        // and the surviving lanes append their symbols to an LDS queue in order (rank = mbcnt of the mask).
-        //
-        // Phase 2, RLE2 + MTF, 64 queued symbols at a time.  Every symbol is RUNA/RUNB or an MTF index, so the
-        // run symbols between two MTF symbols are one run whose bits come straight out of the RUNB ballot; only
-        // MTF symbols are walked one by one.  The first 64 entries of the MTF list live in one VGPR (one entry
-        // per lane): an index below 64 (nearly all of them) is a readlane, a DPP wave shift and a select; the
-        // other entries stay in LDS and are moved there.  The bytes of consecutive MTF symbols collect in one
-        // VGPR (lane e = e-th of them) and are stored together in front of the next run or at the end of the
-        // batch; a run is stored by all lanes at once (nothing in this kernel reads `pre` back).
-        //
-        // A failure seen by phase 1 waits until phase 2 has drained the queue: the first failure in stream
-        // order is the one the reference signals.
-        const uint32_t eob = nsym + 1;
-        const uint64_t endbits = 8 * br.limit;
-        const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(L.inbuf);
-        uint32_t ab_len = 0, ab_val = 0;
-        uint32_t qhead = 0, qn = 0;                 // symbol queue: L.symq[(qhead + i) % BZ_QCAP], i < qn
-        int pend = SEMZ_OK;                         // phase-1 failure waiting for the queue to drain
-        uint32_t pend_detail = 0;
-        bool finished = false;                      // end-of-block symbol seen
-        uint32_t g = 0, k = BZ_GROUP, t = 0, maxlen = 0;
-        P = br.bitpos();
-        in_symbols = true;
-        BZ_STAMP(0);
-
-        auto emit_run = [&](uint32_t front, uint32_t run) {
-            BZ_COUNT(4);
-            for (uint32_t k2 = lane; k2 < run; k2 += 64) pre[n + k2] = (uint8_t)front;
-            n += run;
-        };
-
-        for (;;) {
-            // ---- phase 1: one window ----
-            BZ_STAMP(2);
-            if (!finished && pend == SEMZ_OK && qn <= (uint32_t)BZ_QCAP - 64) {
+            const uint32_t eob = nsym + 1;
+            const uint64_t endbits = 8 * br.limit;
+            const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(L.inbuf);
+            uint32_t produced = 0, consumed_seen = 0;
+            uint32_t g = 0, k = BZ_GROUP, t = 0, maxlen = 0;
+            P = br.bitpos();
+            in_symbols = true;
+            BZ_STAMP(0);
+            for (;;) {
+                // room for one more window of symbols?
+                if (produced - consumed_seen > (uint32_t)BZ_QCAP - 64) {
+                    bool stop = false;
+                    for (;;) {
+                        consumed_seen = BZ_LD(L.sh.consumed);
+                        if (produced - consumed_seen <= (uint32_t)BZ_QCAP - 64) break;
+                        if (BZ_LD(L.sh.abort)) { stop = true; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    BZ_STAMP(3);
+                    if (stop) break;
+                }
                 if (k == (uint32_t)BZ_GROUP) {
-                    if (g >= nsel) { pend = SEMZ_E_BZ_SELECTORS_EXHAUSTED; continue; }
+                    if (g >= nsel) BZ_FAIL(SEMZ_E_BZ_SELECTORS_EXHAUSTED, 0);
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)((L.sel4[g >> 3] >> (4 * (g & 7))) & 15));
                     maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tree[t].maxlen);
                     g++;
@@ -448,6 +463,7 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
                 const bool start = (mask >> lane) & 1;
                 const uint64_t eobm = __builtin_amdgcn_ballot_w64(start && (ev >> 5) == eob);
                 uint64_t qmask = mask;
+                bool finished = false;
                 if (eobm) {
                     const uint32_t e = (uint32_t)__builtin_ctzll(eobm);
                     qmask = mask & ((1ull << e) - 1);
@@ -455,140 +471,194 @@ __global__ __launch_bounds__(64) void bz_decode_kernel(const uint8_t *in, const 
                     finished = true;
                     short_input = false;
                 }
-                if (short_input) pend = SEMZ_EOF;
-                // append the symbols to the queue in order
+                // append the symbols to the queue in order and publish them
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(qmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qmask, 0));
-                if ((qmask >> lane) & 1) L.symq[(qhead + qn + rank) & (BZ_QCAP - 1)] = (uint16_t)(ev >> 5);
-                qn += (uint32_t)__builtin_popcountll(qmask);
+                if ((qmask >> lane) & 1) L.symq[(produced + rank) & (BZ_QCAP - 1)] = (uint16_t)(ev >> 5);
+                produced += (uint32_t)__builtin_popcountll(qmask);
                 k += cnt;
                 P += off;
+                BZ_ST(L.sh.produced, produced);
 #ifdef SEMZ_STAMPS
                 n_acc[1] += cnt;
 #endif
-                if (!finished && pend == SEMZ_OK && qn < 64) { BZ_STAMP(1); continue; }
-            }
-            // ---- phase 2: up to 64 queued symbols ----
-            BZ_STAMP(1);
-            const bool last = finished || pend != SEMZ_OK;
-            const uint32_t m = qn < 64 ? qn : 64;
-            lds_sync();
-            const uint32_t sq = (uint32_t)lane < m ? L.symq[(qhead + lane) & (BZ_QCAP - 1)] : 0u;
-            lds_sync();
-            qhead = (qhead + m) & (BZ_QCAP - 1);
-            qn -= m;
-            const bool valid = (uint32_t)lane < m;
-            const uint64_t bmask = __builtin_amdgcn_ballot_w64(valid && sq == 1);
-            uint64_t mtfmask = __builtin_amdgcn_ballot_w64(valid && sq >= 2);
-            // MTF symbols with run symbols (or a pending run) right below them
-            const uint64_t runmask = __builtin_amdgcn_ballot_w64(valid && sq < 2);
-            uint64_t afterrun = mtfmask & (runmask << 1);
-            if (ab_len) afterrun |= mtfmask & (0 - mtfmask);
-            int err = SEMZ_OK;                       // a failure leaves the walk through the loop condition
-            uint32_t c = 0, outv = 0;                // lane e < c of outv holds the byte of the e-th MTF symbol since the last store
-            // lane 0 takes `c0`, lane l > 0 takes lane l - 1 (the DPP shift leaves `old` in lane 0)
-            auto shr1 = [](uint32_t v, uint32_t c0) {
-                return (uint32_t)__builtin_amdgcn_update_dpp((int)c0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            };
-            auto move_to_front = [&](uint32_t x, uint32_t idx) {
-                const uint32_t sh = shr1(mtf_a, x);
-                mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
-                outv = (uint32_t)lane == c ? x : outv;
-                c++;
-            };
-            // stores the pending MTF bytes; an MTF symbol that arrives with the block full is the reference's failure
-            auto store_pending = [&]() {
-                if (n + c > block_size) { if (err == SEMZ_OK) err = SEMZ_E_BZ_TOO_MANY_CODES; mtfmask = 0; }
-                else if ((uint32_t)lane < c) pre[n + lane] = (uint8_t)outv;
-                n += c;
-                c = 0;
-            };
-            while (mtfmask) {
-                const uint32_t i = (uint32_t)__builtin_ctzll(mtfmask);
-                mtfmask &= ~(1ull << i);
-                if ((afterrun >> i) & 1) {
-                    store_pending();
-                    // the run symbols [lastpos, i) sit between the MTF symbol before and this one
-                    const uint64_t below = ~runmask & ((1ull << i) - 1);
-                    const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
-                    const uint32_t rl = i - lastpos;
-                    ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
-                    ab_len += rl;
-                    const uint32_t run = (ab_val | (1u << (ab_len & 31))) - 1;
-                    if (err != SEMZ_OK) { }
-                    else if (ab_len > (uint32_t)BZ_AB_BOUND) { err = SEMZ_E_BZ_AB_RUN_LENGTH; mtfmask = 0; }
-                    else if (n + run > block_size) { err = SEMZ_E_BZ_AB_RUN_SIZE; mtfmask = 0; }
-                    else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
-                    ab_len = 0;
-                    ab_val = 0;
-                }
-                // move-to-front of entry idx >= 1 (after a failure this still runs once, harmlessly)
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)sq, (int)i) - 1;
-                if (idx < 64) {
-                    move_to_front((uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx), idx);
-                } else {
-                    // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
-                    const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx]);
-                    uint32_t v[3];
-                    for (int c3 = 0; c3 < 3; c3++) {
-                        const uint32_t p = 64 + 64 * c3 + lane;
-                        v[c3] = p < idx ? L.symbols[p] : 0u;
-                    }
-                    lds_sync();
-                    for (int c3 = 0; c3 < 3; c3++) {
-                        const uint32_t p = 64 + 64 * c3 + lane;
-                        if (p < idx) L.symbols[p + 1] = (uint8_t)v[c3];
-                    }
-                    if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
-                    lds_sync();
-                    move_to_front(x, idx);
-                }
-            }
-            store_pending();
-            if (err != SEMZ_OK) BZ_FAIL(err, 0);
-            {
-                // run symbols at the end of the batch stay pending
-                const uint64_t below = ~runmask & (m == 64 ? ~0ull : (1ull << m) - 1);
-                const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
-                const uint32_t rl = m - lastpos;
-                if (rl) {
-                    if (ab_len + rl > (uint32_t)BZ_AB_BOUND) BZ_FAIL(SEMZ_E_BZ_AB_RUN_LENGTH, 0);
-                    ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
-                    ab_len += rl;
-                }
-            }
-            if (last && qn == 0) {
-                if (pend != SEMZ_OK) BZ_FAIL(pend, pend_detail);
-                if (ab_len) {                        // the run in front of the end-of-block symbol
-                    const uint32_t run = (ab_val | (1u << ab_len)) - 1;
-                    if (n + run > block_size) BZ_FAIL(SEMZ_E_BZ_AB_RUN_SIZE, 0);
-                    emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
-                }
-                break;
+                BZ_STAMP(1);
+                if (short_input) BZ_FAIL(SEMZ_EOF, 0);
+                if (finished) break;
             }
         }
-        BZ_STAMP(2);
-        // decode-bzip2-bwt's precondition; deliberate divergence, see DESIGN.md
-        if (n == 0 ? orig >= block_size : orig >= n) BZ_FAIL(SEMZ_E_BZ_ORIGPTR, orig);
-    }
-done:
-#ifdef SEMZ_STAMPS
-    if (lane == 0) {
-        for (int i = 0; i < 4; i++) atomicAdd(&g_bz_stamps[i], (unsigned long long)t_acc[i]);
-        for (int i = 0; i < 6; i++) atomicAdd(&g_bz_stamps[4 + i], (unsigned long long)n_acc[i]);
-        atomicAdd(&g_bz_stamps[10], 1ull);
-        atomicAdd(&g_bz_stamps[11], (unsigned long long)n);
-    }
-#endif
-    if (lane == 0) {
-        bz_meta m;
-        m.n = n; m.orig = orig; m.randomized = randomized; m.want_crc = want_crc;
-        m.status = status; m.detail = detail;
-        m.end_bit = (in_symbols ? P : br.bitpos()) - 8 * amis;
-        m.out_len = 0; m.out_off = 0;
-        meta[u] = m;
-    }
+    done:
+        L.sh.status = status;
+        L.sh.detail = detail;
+        L.sh.orig = orig;
+        L.sh.randomized = randomized;
+        L.sh.want_crc = want_crc;
+        {
+            const uint64_t end_bit = (in_symbols ? P : br.bitpos()) - 8 * amis;
+            L.sh.end_lo = (uint32_t)end_bit;
+            L.sh.end_hi = (uint32_t)(end_bit >> 32);
+        }
+        BZ_ST(L.sh.done, 1);
 #undef BZ_FAIL
 #undef BZ_EOFCHK
+    } else {
+        // ================= consumer =================
+        uint32_t n = 0;
+        int err = SEMZ_OK;
+        // wait for the MTF alphabet (or for a header that failed)
+        while (!BZ_LD(L.sh.hdr_ready) && !BZ_LD(L.sh.done)) __builtin_amdgcn_s_sleep(8);
+        if (BZ_LD(L.sh.hdr_ready)) {
+            // inverse-MTF list: lane i of mtf_a holds entry i < 64; entries 64 .. 255 stay in L.symbols
+            uint32_t mtf_a = L.symbols[lane];
+            uint32_t ab_len = 0, ab_val = 0, consumed = 0, produced_seen = 0;
+            auto emit_run = [&](uint32_t front, uint32_t run) {
+                BZ_COUNT(4);
+                // the counter goes through readfirstlane so that the loop keeps a uniform exit: behind a divergent
+                // exit every scalar that is live across the loop would count as divergent
+                for (uint32_t k0 = 0; k0 < run; k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k0 + 64)))
+                    if (k0 + lane < run) pre[n + k0 + lane] = (uint8_t)front;
+                n += run;
+            };
+            BZ_STAMP(4);
+            for (;;) {
+                uint32_t avail = produced_seen - consumed;
+                if (avail < 64) {
+                    for (;;) {
+                        const uint32_t dn = BZ_LD(L.sh.done);            // read before `produced`: final if set
+                        produced_seen = BZ_LD(L.sh.produced);
+                        avail = produced_seen - consumed;
+                        if (avail >= 64 || dn) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    BZ_STAMP(4);
+                }
+                const uint32_t m = avail < 64 ? avail : 64;
+                if (m == 0) break;                                       // done and drained
+                const uint32_t sq = (uint32_t)lane < m ? L.symq[(consumed + lane) & (BZ_QCAP - 1)] : 0u;
+                consumed += m;
+                const bool valid = (uint32_t)lane < m;
+                const uint64_t bmask = __builtin_amdgcn_ballot_w64(valid && sq == 1);
+                uint64_t mtfmask = __builtin_amdgcn_ballot_w64(valid && sq >= 2);
+                BZ_ST(L.sh.consumed, consumed);                          // sq is in registers: the slots are free
+                // MTF symbols with run symbols (or a pending run) right below them
+                const uint64_t runmask = __builtin_amdgcn_ballot_w64(valid && sq < 2);
+                uint64_t afterrun = mtfmask & (runmask << 1);
+                if (ab_len) afterrun |= mtfmask & (0 - mtfmask);
+                bool too_many = false;
+                uint32_t c = 0, outv = 0;            // lane e < c of outv holds the byte of the e-th MTF symbol since the last store
+                // lane 0 takes `c0`, lane l > 0 takes lane l - 1 (the DPP shift leaves `old` in lane 0)
+                auto shr1 = [](uint32_t v, uint32_t c0) {
+                    return (uint32_t)__builtin_amdgcn_update_dpp((int)c0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                };
+                auto move_to_front = [&](uint32_t x, uint32_t idx) {
+                    const uint32_t sh = shr1(mtf_a, x);
+                    mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
+                    outv = (uint32_t)lane == c ? x : outv;
+                    c++;
+                };
+                // stores the pending MTF bytes; an MTF symbol that arrives with the block full is the reference's
+                // failure.  Written without control flow around the scalars: a value merged behind the lane-masked
+                // store would count as divergent and pull the whole walk into VGPRs.
+                auto store_pending = [&]() {
+                    const bool over = n + c > block_size;
+                    too_many |= over;
+                    mtfmask = over ? 0 : mtfmask;
+                    if (!over && (uint32_t)lane < c) pre[n + lane] = (uint8_t)outv;
+                    n += c;
+                    c = 0;
+                    // the optimiser threads the select above into the branches of the store all the same: pin it
+                    mtfmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mtfmask >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mtfmask);
+                };
+                while (mtfmask) {                    // a failure leaves the walk through this condition
+                    const uint32_t i = (uint32_t)__builtin_ctzll(mtfmask);
+                    mtfmask &= ~(1ull << i);
+                    if ((afterrun >> i) & 1) {
+                        store_pending();
+                        // the run symbols [lastpos, i) sit between the MTF symbol before and this one
+                        const uint64_t below = ~runmask & ((1ull << i) - 1);
+                        const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
+                        const uint32_t rl = i - lastpos;
+                        ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
+                        ab_len += rl;
+                        const uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ab_val | (1u << (ab_len & 31))) - 1));
+                        if (too_many) { }
+                        else if (ab_len > (uint32_t)BZ_AB_BOUND) { err = SEMZ_E_BZ_AB_RUN_LENGTH; mtfmask = 0; }
+                        else if (n + run > block_size) { err = SEMZ_E_BZ_AB_RUN_SIZE; mtfmask = 0; }
+                        else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
+                        ab_len = 0;
+                        ab_val = 0;
+                    }
+                    // move-to-front of entry idx >= 1 (after a failure this still runs once, harmlessly)
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)sq, (int)i) - 1;
+                    if (idx < 64) {
+                        move_to_front((uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx), idx);
+                    } else {
+                        // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
+                        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
+                        uint32_t v[3];
+                        for (int c3 = 0; c3 < 3; c3++) {
+                            const uint32_t p = 64 + 64 * c3 + lane;
+                            v[c3] = p < idx ? L.symbols[p] : 0u;
+                        }
+                        lds_sync();
+                        for (int c3 = 0; c3 < 3; c3++) {
+                            const uint32_t p = 64 + 64 * c3 + lane;
+                            if (p < idx && p < 255) L.symbols[p + 1] = (uint8_t)v[c3];
+                        }
+                        if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
+                        lds_sync();
+                        move_to_front(x, idx);
+                    }
+                }
+                store_pending();
+                if (err == SEMZ_OK && too_many) err = SEMZ_E_BZ_TOO_MANY_CODES;    // a run failure came first if there is one
+                if (err == SEMZ_OK) {
+                    // run symbols at the end of the batch stay pending
+                    const uint64_t below = ~runmask & (m == 64 ? ~0ull : (1ull << m) - 1);
+                    const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
+                    const uint32_t rl = m - lastpos;
+                    if (ab_len + rl > (uint32_t)BZ_AB_BOUND) err = SEMZ_E_BZ_AB_RUN_LENGTH;
+                    else if (rl) {
+                        ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
+                        ab_len += rl;
+                    }
+                }
+                BZ_STAMP(2);
+                if (err != SEMZ_OK) break;
+            }
+            if (err != SEMZ_OK) BZ_ST(L.sh.abort, 1);
+            while (!BZ_LD(L.sh.done)) __builtin_amdgcn_s_sleep(8);
+            if (err == SEMZ_OK && (int)L.sh.status == SEMZ_OK && ab_len) {
+                // the run in front of the end-of-block symbol
+                const uint32_t run = (ab_val | (1u << ab_len)) - 1;
+                if (n + run > block_size) err = SEMZ_E_BZ_AB_RUN_SIZE;
+                else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
+            }
+        }
+        // `done` has been seen: the producer's fields are final
+        int status = err != SEMZ_OK ? err : (int)BZ_LD(L.sh.status);
+        uint32_t detail = err != SEMZ_OK ? 0u : BZ_LD(L.sh.detail);
+        const uint32_t orig = BZ_LD(L.sh.orig);
+        // decode-bzip2-bwt's precondition; deliberate divergence, see DESIGN.md
+        if (status == SEMZ_OK && (n == 0 ? orig >= block_size : orig >= n)) { status = SEMZ_E_BZ_ORIGPTR; detail = orig; }
+        if (lane == 0) {
+            bz_meta m;
+            m.n = n; m.orig = orig; m.randomized = L.sh.randomized; m.want_crc = L.sh.want_crc;
+            m.status = status; m.detail = detail;
+            m.end_bit = ((uint64_t)L.sh.end_hi << 32) | L.sh.end_lo;
+            m.out_len = 0; m.out_off = 0;
+            meta[u] = m;
+        }
+    }
+#ifdef SEMZ_STAMPS
+    if (lane == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&g_bz_stamps[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 6; i++) atomicAdd(&g_bz_stamps[5 + i], (unsigned long long)n_acc[i]);
+        if (wid == 1) atomicAdd(&g_bz_stamps[11], 1ull);
+    }
+#endif
+#undef BZ_LD
+#undef BZ_ST
 }
 
 // ---- RLE1 state machine (decode-bzip2-rle1, bzip2.lisp:59-102) ----
@@ -914,7 +984,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
         attr_set = true;
     }
     semz_span_begin(c, "bz_decode_kernel");
-    bz_decode_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre);
+    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre);
     semz_span_end(c);
     semz_span_begin(c, "bz_bwt_kernel");
     bz_bwt_kernel<<<nunits, 1024, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,

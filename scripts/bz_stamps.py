@@ -14,8 +14,8 @@ lib = _lib.load()
 bench.main()
 st = (C.c_ulonglong * 16)()
 assert lib.semz_debug_bz_stamps(st, 1) == 0
-b = st[10] or 1
-print(f"blocks {b}  header {st[0] / b / 1e6:.2f}  Huffman phase {st[1] / b / 1e6:.2f}  MTF phase {st[2] / b / 1e6:.2f} Mticks/block")
-print(f"per block: windows {st[4] / b:.0f} symbols {st[5] / b:.0f} long codes {st[6] / b:.0f} stages {st[7] / b:.0f} "
-      f"runs {st[8] / b:.0f} run pieces {st[9] / b:.0f} bytes {st[11] / b:.0f}")
-print(f"ticks/symbol: Huffman {st[1] / max(1, st[5]):.0f}  MTF {st[2] / max(1, st[5]):.0f}   symbols/window {st[5] / max(1, st[4]):.1f}")
+b = st[11] or 1
+print(f"blocks {b}  Mticks/block: header {st[0] / b / 1e6:.2f}  Huffman wave busy {st[1] / b / 1e6:.2f} waiting {st[3] / b / 1e6:.2f}  "
+      f"MTF wave busy {st[2] / b / 1e6:.2f} waiting {st[4] / b / 1e6:.2f}")
+print(f"per block: windows {st[5] / b:.0f} symbols {st[6] / b:.0f} windows with long codes {st[7] / b:.0f} stages {st[8] / b:.0f} runs {st[9] / b:.0f}")
+print(f"ticks/symbol: Huffman {st[1] / max(1, st[6]):.0f}  MTF {st[2] / max(1, st[6]):.0f}   symbols/window {st[6] / max(1, st[5]):.1f}")
