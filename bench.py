@@ -91,7 +91,7 @@ def _split(fmt_id, data):
     return arr, info
 
 
-def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64"):
+def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64", replicate=1):
     """Returns dict(data, uarr, nunits, total_out, total_in, kind, blobs, out_cap)."""
     from decompress_amd import _lib
     if fmt in ("gzip", "zlib"):
@@ -113,7 +113,8 @@ def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64"):
     # bzip2 / xz: `nunits` streams of `unit_bytes`; the blocks inside are found by the host splitter
     jobs = [(i, i + 1, unit_bytes, seed) + ((check,) if fmt == "xz" else ()) for i in range(nunits)]
     parts = _pool_map(_make_bzip2_streams if fmt == "bzip2" else _make_xz_streams, jobs, workers)
-    blobs = [b for p in parts for b in p]
+    blobs = [b for p in parts for b in p] * replicate
+    nunits *= replicate
     data = b"".join(blobs)
     uarr, info = _split(_lib.FMT_BZIP2 if fmt == "bzip2" else _lib.FMT_XZ, data)
     total_out = nunits * unit_bytes
@@ -128,15 +129,14 @@ def cpu_baseline(fmt, blobs, sample_out, budget_s=12.0):
     fmt_id = {"gzip": 2, "zlib": 1, "bzip2": 3, "xz": 8}[fmt]
     t0 = time.perf_counter()
     done = 0
-    for b in blobs:
+    while time.perf_counter() - t0 <= budget_s:            # a bounded sample: about budget_s of CPU work
+        b = blobs[done % len(blobs)]
         r, o = oracle.decompress(fmt_id, b, True, cap=sample_out + 16)
         assert r.status == 0 and len(o) == sample_out
         done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
     dt = time.perf_counter() - t0
     return {"value": done * sample_out / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{done} of the same {fmt} inputs ({done * sample_out / 2**20:.0f} MiB out) through oracle/ "
+            "sample": f"{done} decodes cycling over the same {fmt} inputs ({done * sample_out / 2**20:.0f} MiB out) through oracle/ "
                       f"(C restatement of the reference), 1 thread, {dt:.1f} s"}
 
 
@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--unit-bytes", type=int, default=0)
     ap.add_argument("--check", default="crc64", choices=["crc64", "sha256", "crc32", "none"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--replicate", type=int, default=0,
+                    help="bzip2/xz: decode every generated stream this many times over (bounds corpus generation time)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,14 +171,18 @@ def main():
                     "(BASELINE configs[2] shape: 512 MiB of the 4 GiB per GPU), block and stream CRCs verified")
     else:
         nunits, unit_bytes = a.units or 16, a.unit_bytes or (16 << 20)
-        workload = (f"{nunits} xz streams of {unit_bytes >> 20} MiB per GPU, 1 MiB LZMA2 blocks + x86 BCJ, "
-                    f"check {a.check} verified (BASELINE configs[3] shape)")
+        a.replicate = a.replicate or 4
+        workload = (f"{nunits * a.replicate} xz streams of {unit_bytes >> 20} MiB per GPU ({nunits} distinct, each {a.replicate} times), "
+                    f"1 MiB LZMA2 blocks + x86 BCJ, check {a.check} verified (BASELINE configs[3] shape)")
+    rep = max(1, a.replicate) if a.format in ("bzip2", "xz") else 1
+    if a.format == "bzip2" and rep > 1:
+        workload = workload.replace(" per GPU,", f" per GPU ({nunits} distinct, each {rep} times),").replace(f"{nunits} bzip2", f"{nunits * rep} bzip2", 1)
 
     from decompress_amd import _lib
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, min(16, ncpu // max(1, world)))
     t_gen = time.perf_counter()
-    W = build_workload(a.format, nunits, unit_bytes, 0x5EED0001 + rank * 1000003, workers, a.check)
+    W = build_workload(a.format, nunits, unit_bytes, 0x5EED0001 + rank * 1000003, workers, a.check, rep)
     t_gen = time.perf_counter() - t_gen
     data, uarr, nun, total_out, total_in, kind, blobs = (W[k] for k in ("data", "uarr", "nunits", "total_out", "total_in", "kind", "blobs"))
 
@@ -252,6 +258,16 @@ def main():
         kname = max(avg, key=avg.get)
         kavg = avg[kname]
         achieved = (total_in + total_out) / (kavg * 1e-3) / 1e9
+        # HBM bytes per launch of that kernel from the committed PMC passes of this same command
+        # (scripts/pmc_traffic.py; rocprofv3 cannot run inside the timed process)
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc_key = f"{a.format}:{nun}x{unit_bytes}:{kname}"
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                ent = json.load(f).get(pmc_key)
+            if ent:
+                traffic, traffic_src = ent["traffic_bytes_per_launch"], f"profiles/pmc_traffic.json[{pmc_key}]"
         line = {
             "metric": METRIC, "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
@@ -260,7 +276,7 @@ def main():
                        "compressed_bytes_per_gpu": total_in, "decompressed_bytes_per_gpu": total_out,
                        "sharding": f"units by rank x{world}, no collective", "corpus_gen_s": round(t_gen, 1)},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": total_in + total_out,
                          "kernel_ms_avg": round(kavg, 4),
                          "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname}},
