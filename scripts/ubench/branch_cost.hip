@@ -93,6 +93,19 @@ __global__ void k_lds_rfl(unsigned long long *out, int iters)
     if (x == 12345) out[1000] = 1;
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
 }
+// a mixed scalar-heavy body (the shape of the decode loops): how does the time grow with waves per SIMD?
+__global__ void k_mix(unsigned long long *out, int iters)
+{
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned x = threadIdx.x, s = 0, a = iters;
+    for (int i = 0; i < iters; i++) {
+        REP16(asm volatile("v_readlane_b32 %0, %2, %0\n s_and_b32 %0, %0, 63\n s_add_u32 %1, %1, %0\n s_lshr_b32 %1, %1, 1\n v_add_u32 %2, %2, %1\n s_cmp_eq_u32 %1, 0x7fffffff\n s_cbranch_scc1 0\n v_xor_b32 %2, %2, %1\n"
+                           : "+s"(s), "+s"(a), "+v"(x) : : "scc");)
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (x == 12345) out[1000] = 1;
+    if (threadIdx.x == 0) out[blockIdx.x & 1023] = t1 - t0 + (s == 12345);
+}
 int main()
 {
     unsigned long long *d, h[1];
@@ -111,6 +124,15 @@ int main()
         RUN(k_dpp, "s_nop 1 + dpp wave_shr (dependent)");
         RUN(k_lds, "dependent ds_read per lane");
         RUN(k_lds_rfl, "ds_read + readfirstlane (dependent)");
+    }
+    for (int g = 256; g <= 16384; g *= 2) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        k_mix<<<g, 64>>>(d, 20000); hipDeviceSynchronize();
+        hipEventRecord(e0); k_mix<<<g, 64>>>(d, 20000); hipEventRecord(e1); hipDeviceSynchronize();
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+        printf("mixed body: %5d waves (%.2f per SIMD)  %8.3f ms  %6.1f ticks per 8-instruction group in wave 0\n", g, g / 1024.0, ms, (double)h[0] / (16.0 * 20000));
+        fflush(stdout);
     }
     return 0;
 }
