@@ -42,6 +42,18 @@
 // codes longer than the root and for the table fill.
 #include "semz_device.h"
 
+#ifdef SEMZ_STAMPS
+// diagnostic build only (make STAMPS=1): per-phase shader-clock totals summed over all units
+__device__ unsigned long long g_stamps[16];
+#define STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0}; uint32_t n_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define COUNT(i, n) do { n_acc[i] += (n); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define COUNT(i, n) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int LIT_ROOT_BITS = 10;
@@ -92,6 +104,7 @@ struct __align__(16) UnitLds {
     uint8_t clen_root[1 << CLEN_ROOT_BITS];
     uint8_t lens[320];
     uint8_t clens[32];
+    uint8_t flags[64];
     TreeMeta lit, dist, clen;
 };
 static_assert(sizeof(UnitLds) <= 10240, "sixteen units per CU");
@@ -278,6 +291,19 @@ __device__ __forceinline__ uint32_t ld_bytes_le(const uint8_t *p, int n)
 // from SGPRs to VGPRs.  Emits no instruction.
 __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); }
 
+// wave-wide inclusive prefix maximum of unsigned values (identity 0)
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 // wave-wide inclusive prefix sum (DPP row shifts, then the two row broadcasts)
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
 {
@@ -406,8 +432,10 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
     };
     auto short_of = [&](uint32_t n) -> bool { return endbits - P < (uint64_t)n; };
 
+    STAMP_DECL
     // ---- main loop: one round per iteration ----
     for (;;) {
+        STAMP(5);
         // scripts/check_uniform.sh: without this pin the optimiser's merge of P behind the lane-masked stores of the
         // round counts as divergent and the whole decoder state moves to VGPRs
         P = uni(P);
@@ -422,6 +450,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             if (state == ST_HUFF) {
                 if (dist_mode != MODE_LITONLY && endbits - P >= 64 + TOKEN_BITS) {
                     // ---- window decode: lane l takes the token that would start at bit P + l ----
+                    COUNT(0, 1);
                     const uint64_t bp = P + lane;
                     const uint32_t d = (uint32_t)(bp >> 5), sh = (uint32_t)bp & 31;
                     const uint32_t w0 = ring32[d & (IN_RING / 4 - 1)], w1 = ring32[(d + 1) & (IN_RING / 4 - 1)],
@@ -482,6 +511,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     if (kept && !islit) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
                     join_lanes();
                     ntok += (uint32_t)__builtin_popcountll(matchmask & keep);
+                    COUNT(1, (uint32_t)__builtin_popcountll(keep));
                     P += adv;
                     // the scalar step may queue a match and write a literal: only inside the round's limits
                     if (!careful || ntok >= (uint32_t)QCAP || rbytes >= (uint32_t)ROUND_BYTES) continue;
@@ -489,6 +519,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                 }
                 // ---- one token by the scalar step with every check (decode-huffman-data, deflate.lisp:313-338) ----
                 {
+                    COUNT(2, 1);
                     uint32_t x = rd32(P);
                     uint32_t e = uni((uint32_t)L.lit_root[x & ((1u << LIT_ROOT_BITS) - 1)]);
                     uint32_t cl = e & 15;
@@ -619,6 +650,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
         }
 #undef FAIL
         lds_sync();
+        STAMP(0);
+        COUNT(3, 1);
 
         // ---- resolve the round's tokens ----
         const uint64_t pos0 = pos, pos1 = pos + rbytes;
@@ -627,63 +660,61 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
         if (ntok) {
             const uint2 tk = lane < ntok ? L.queue[lane] : make_uint2(0, 0);
             const bool is_match = (tk.x & 3) == T_MATCH;
-            const bool is_far = is_match && ((int64_t)(pos0 + (tk.x >> 16)) - (int64_t)tk.y) < near_lo;
-            uint64_t farm = __builtin_amdgcn_ballot_w64(is_far);
-            uint64_t nearm = __builtin_amdgcn_ballot_w64(is_match && !is_far);
+            const uint32_t tlen = (tk.x >> 2) & 0x3FFF, tdoff = tk.x >> 16;
+            const int32_t tsrel = (int32_t)tdoff - (int32_t)tk.y;           // source position relative to pos0
+            // A match whose whole source lies before the round's first byte depends on nothing produced in this
+            // round (the round's literals are already in the ring).  All such matches are resolved together with
+            // lanes = bytes: an exclusive prefix sum of their lengths lays their bytes out back to back, and for
+            // every 64 of those bytes a lane finds its match (flag scatter through LDS + max-scan), fetches that
+            // match's fields with bpermute and loads its byte -- from the ring, from HBM (older than the ring:
+            // written by this wave, read back through L2) or from the preset dictionary.  Four such 64-byte chunks
+            // are in flight per pass.  The other matches read bytes of this round and follow, in token order.
+            const bool indep = is_match && tsrel + (int32_t)tlen <= 0;
+            const uint32_t plen = indep ? tlen : 0u;
+            const uint32_t pincl = wave_scan_add(plen), poff = pincl - plen;
+            const uint32_t PB = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+            uint64_t nearm = __builtin_amdgcn_ballot_w64(is_match && !indep);
             uint64_t rawm = __builtin_amdgcn_ballot_w64((tk.x & 3) == T_RAW);
-            // far matches: no byte of the source was produced in this round, so the gathers of four
-            // tokens (64 bytes each) are put in flight together
-            while (farm) {
-                uint32_t fl[4], fp[4], gv[4], lv[4];
-                int64_t fs[4];
-                bool neg = false;
+            COUNT(4, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(indep))); COUNT(5, (uint32_t)__builtin_popcountll(nearm));
+            uint32_t carry = 0;                 // queue lane of the match that covers the first byte of the next chunk
+            for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
+                uint32_t gv[4], ov[4], di[4];
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const uint64_t more = farm;
-                    const uint32_t j = more ? (uint32_t)__builtin_ctzll(more) : 0u;
-                    farm &= farm - 1;
-                    const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)tk.x, (int)j);
-                    const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)tk.y, (int)j);
-                    fl[b] = more ? (tx >> 2) & 0x3FFF : 0;
-                    fp[b] = tx >> 16;
-                    fs[b] = (int64_t)(pos0 + fp[b]) - (int64_t)ty;
-                }
-                // unconditional loads (HBM through L2: the bytes were written by this wave; LDS ring), selected below
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int64_t s = fs[b] + lane;
-                    const bool act = lane < fl[b];
-                    const bool useg = act && s >= 0 && s < near_lo;
-                    gv[b] = __hip_atomic_load(useg ? ob + s : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    lv[b] = L.ring[(uint32_t)((uint64_t)s + shift) & RING_MASK];
-                    neg = neg || (act && s < 0);
-                }
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int64_t s = fs[b] + lane;
-                    if (lane < fl[b] && s >= 0)
-                        L.ring[(uint32_t)(pos0 + fp[b] + lane + shift) & RING_MASK] = (uint8_t)(s >= near_lo ? lv[b] : gv[b]);
-                }
-                if (__builtin_amdgcn_ballot_w64(neg)) {                // preset dictionary bytes (zlib FDICT, deflate prefix)
-#pragma unroll
-                    for (int b = 0; b < 4; b++)
-                        if (lane < fl[b] && fs[b] + (int64_t)lane < 0)
-                            L.ring[(uint32_t)(pos0 + fp[b] + lane + shift) & RING_MASK] = prefix_end[fs[b] + (int64_t)lane];
-                }
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    // the rest of a match longer than 64 bytes (uniform trip count)
-                    for (uint32_t k0 = 64; k0 < fl[b]; k0 = uni(k0 + 64)) {
-                        const uint32_t k = k0 + lane;
-                        if (k < fl[b]) {
-                            const int64_t s = fs[b] + k;
-                            uint32_t v;
-                            if (s >= near_lo) v = L.ring[(uint32_t)((uint64_t)s + shift) & RING_MASK];
-                            else if (s < 0) v = prefix_end[s];
-                            else v = __hip_atomic_load(ob + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            L.ring[(uint32_t)(pos0 + fp[b] + k + shift) & RING_MASK] = (uint8_t)v;
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t lo = cb + 64u * c;
+                    gv[c] = 0; ov[c] = 0; di[c] = 0xFFFFFFFFu;
+                    if (lo < PB) {
+                        lds_sync();
+                        L.flags[lane] = 0;
+                        lds_sync();
+                        if (indep && poff - lo < 64u) L.flags[poff - lo] = (uint8_t)(lane + 1);
+                        join_lanes();
+                        lds_sync();
+                        const uint32_t f = L.flags[lane];
+                        const uint32_t t = wave_scan_max(f ? ((lane + 1) << 8) | (f - 1) : 0u);
+                        const uint32_t j = t ? (t & 0xFF) : carry;
+                        carry = (uint32_t)__builtin_amdgcn_readlane((int)j, 63);
+                        const int32_t srel = __builtin_amdgcn_ds_bpermute((int)(4 * j), tsrel);
+                        const uint32_t doff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * j), (int)tdoff);
+                        const uint32_t po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * j), (int)poff);
+                        const uint32_t k = lo + lane - po;
+                        const bool act = lo + lane < PB;
+                        const int64_t sabs = (int64_t)pos0 + srel + (int64_t)k;
+                        const bool useg = act && sabs >= 0 && sabs < near_lo;
+                        const bool neg = act && sabs < 0;
+                        gv[c] = __hip_atomic_load(useg ? ob + sabs : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ov[c] = L.ring[(uint32_t)((uint64_t)sabs + shift) & RING_MASK];
+                        if (__builtin_amdgcn_ballot_w64(neg)) {             // preset dictionary bytes (zlib FDICT, deflate prefix)
+                            if (neg) ov[c] = prefix_end[sabs];
+                            join_lanes();
                         }
+                        if (act) di[c] = (((uint32_t)pos0 + doff + k + shift) & RING_MASK) | (useg ? 0x80000000u : 0u);
                     }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (di[c] != 0xFFFFFFFFu) L.ring[di[c] & RING_MASK] = (uint8_t)((di[c] >> 31) ? gv[c] : ov[c]);
+                    join_lanes();
                 }
             }
             // stored spans straight from the input
@@ -729,6 +760,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
         }
         pos = pos1;
         lds_sync();
+        STAMP(2);
 
         // ---- flush the ring ----
         {
@@ -765,6 +797,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             flushed = uni(flushed);
         }
         lds_sync();
+        STAMP(3);
 
         // ---- table construction for the next block ----
         if (ev == EV_DYN || ev == EV_FIXED) {
@@ -860,6 +893,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             lds_sync();
         }
 
+        STAMP(4);
+
         // ---- unit end: trailer and results ----
         if (ev == EV_DONE) {
             semz_tail t{};
@@ -893,6 +928,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             if (lane == 0) {
                 results[u] = r;
                 tails[u] = t;
+#ifdef SEMZ_STAMPS
+                for (int i = 0; i < 6; i++) atomicAdd(&g_stamps[i], (unsigned long long)t_acc[i]);
+                for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[6 + i], (unsigned long long)n_acc[i]);
+                atomicAdd(&g_stamps[14], 1ull);
+#endif
             }
             break;
         }
@@ -900,6 +940,18 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
 }
 
 } // namespace
+
+#ifdef SEMZ_STAMPS
+extern "C" int semz_debug_stamps(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" void semz_launch_inflate(const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
                                     uint8_t *d_out, semz_result *d_results, semz_tail *d_tails,
