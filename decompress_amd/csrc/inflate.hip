@@ -487,6 +487,25 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const uint32_t ooff = rbytes + incl - ol;                  // output offset inside the round
                     const uint64_t matchmask = __builtin_amdgcn_ballot_w64(ismatch);
                     const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
+                    {
+                        // the usual window: no token for the scalar step, everything fits the round: keep it whole
+                        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                        const uint32_t nm = (uint32_t)__builtin_popcountll(matchmask);
+                        bool whole = (__builtin_amdgcn_ballot_w64(stop) & mask) == 0 && rbytes + total <= (uint32_t)ROUND_BYTES &&
+                                     ntok + nm <= (uint32_t)QCAP && room >= (uint32_t)ROUND_BYTES && wsize >= 32768u;
+                        if (whole && avail < 32768u) whole = __builtin_amdgcn_ballot_w64(ismatch && distance > avail + ooff) == 0;
+                        if (whole) {
+                            if (start && islit) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
+                            join_lanes();
+                            if (ismatch) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                            join_lanes();
+                            COUNT(1, (uint32_t)__builtin_popcountll(mask));
+                            rbytes += total;
+                            ntok += nm;
+                            P += off;
+                            continue;
+                        }
+                    }
                     const uint32_t have = avail + ooff;                        // deflate.lisp:329-331
                     const bool hard = start && (stop || (ismatch && distance > (have < wsize ? have : wsize)) ||
                                                 (uint64_t)ooff + ol > (uint64_t)room);
