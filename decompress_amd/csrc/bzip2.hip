@@ -9,10 +9,10 @@
 //   decode-bzip2-rle1 + block CRC                   bzip2.lisp:59-102, 507-524
 //
 // Kernel sequence (all device-resident, no host round trip):
-//   bz_decode_kernel  one wave per block: header, canonical trees in LDS, the
-//                     bit-serial Huffman+RLE2 decode with the inverse MTF fused
-//                     in (the 256-byte MTF stack lives in registers, 4 bytes per
-//                     lane, and is rotated with cross-lane moves)
+//   bz_decode_kernel  two waves per block: one parses the header and decodes the
+//                     Huffman symbols (64-bit windows, every lane a bit offset)
+//                     into an LDS queue, the other expands RLE2 runs and applies
+//                     the inverse MTF (list in a VGPR, DPP shifts)
 //   bz_bwt_kernel     one 1024-thread workgroup per block: byte histogram,
 //                     prefix sums, stable counting-sort scatter that builds the
 //                     merged (next << 8 | byte) vector, then the inverse-BWT walk

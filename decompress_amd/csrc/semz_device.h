@@ -1,11 +1,10 @@
 // semz_device.h -- device-side helpers shared by the gfx950 kernels.
 //
-// Execution model used by every decode kernel in this library: one workgroup
-// = one 64-lane wavefront; a wavefront is split into 64/G "groups" of G
-// consecutive lanes and each group owns one unit.  Lane 0 of a group (the
-// "leader") runs the bit-serial entropy decode; all G lanes run the
-// data-parallel parts (table construction, match copies, ring flushes).
-// Because a workgroup is a single wave, LDS hand-offs between lanes need no
+// Execution model of the decode kernels: a unit (deflate member, bzip2 block,
+// LZMA2 block) is decoded by one 64-lane wavefront (bzip2: two) whose control
+// state is wave-uniform; the lanes run the data-parallel parts (speculative
+// decode at every bit offset of a window, table construction, match copies,
+// ring flushes).  Inside one wave LDS hand-offs between lanes need no
 // s_barrier: LDS operations of one wave execute in program order, and
 // lds_sync() only stops the compiler from moving LDS accesses across it.
 #pragma once
