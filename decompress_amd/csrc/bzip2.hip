@@ -932,23 +932,67 @@ __global__ void bz_offsets_kernel(const semz_unit *units, uint32_t nunits, bz_me
 __global__ __launch_bounds__(1024) void bz_rle1_kernel(uint32_t nunits, const bz_meta *meta, const uint8_t *post_all,
                                                        const bz_seg *seg_all, uint8_t *out)
 {
+    // One thread per segment (their entry states and output offsets come from bz_bwt_kernel).  The threads of
+    // a wave walk segments that lie ~900 bytes apart, so byte-wise loads and stores would touch 64 different
+    // cache lines per instruction, each of them again for every byte.  Instead a thread takes its input one
+    // whole 64-byte line at a time into registers, and collects its output in a 64-bit register that is
+    // stored with one aligned 8-byte store.
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
     const bz_meta m = meta[u];
     if (m.status != SEMZ_OK) return;
     const uint32_t n = m.n, tid = threadIdx.x;
-    const uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
+    const uint8_t *post = post_all + (size_t)u * BZ_STRIDE;              // 64-byte aligned (BZ_STRIDE is a multiple of 64)
     const bz_seg g = seg_all[(size_t)u * BZ_SEGS + tid];
     uint8_t *o = out + m.out_off + g.off;
     const uint32_t seglen = (n + BZ_SEGS - 1) / BZ_SEGS;
     const uint32_t sbeg = tid * seglen < n ? tid * seglen : n;
     const uint32_t send = sbeg + seglen < n ? sbeg + seglen : n;
     Rle1 st = {g.last, g.reps};
-    for (uint32_t i = sbeg; i < send; i++) {
-        uint32_t ob, k = rle1_step(st, post[i], ob);
-        for (uint32_t j = 0; j < k; j++) o[j] = (uint8_t)ob;
-        o += k;
+    uint64_t acc = 0;            // pending output bytes, little-endian
+    uint32_t nacc = 0;
+    bool aligned = ((uintptr_t)o & 7) == 0;
+    auto emit = [&](uint32_t byte, uint32_t k) {
+        while (k) {
+            if (!aligned) {
+                *o++ = (uint8_t)byte;
+                k--;
+                aligned = ((uintptr_t)o & 7) == 0;
+            } else if (nacc == 0 && k >= 8) {
+                *reinterpret_cast<uint64_t *>(o) = 0x0101010101010101ull * byte;
+                o += 8;
+                k -= 8;
+            } else {
+                acc |= (uint64_t)byte << (8 * nacc);
+                k--;
+                if (++nacc == 8) {
+                    *reinterpret_cast<uint64_t *>(o) = acc;
+                    o += 8;
+                    acc = 0;
+                    nacc = 0;
+                }
+            }
+        }
+    };
+    for (uint32_t line = sbeg & ~63u; line < send; line += 64) {
+        uint32_t w[16];
+        const uint4 *lp = reinterpret_cast<const uint4 *>(post + line);      // the scratch row is BZ_STRIDE long: the last line exists
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 x = lp[q];
+            w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const uint32_t i = line + j;
+            if (i >= sbeg && i < send) {
+                uint32_t ob;
+                const uint32_t k = rle1_step(st, (w[j >> 2] >> (8 * (j & 3))) & 0xFF, ob);
+                emit(ob, k);
+            }
+        }
     }
+    for (uint32_t q = 0; q < nacc; q++) o[q] = (uint8_t)(acc >> (8 * q));
 }
 
 } // namespace
