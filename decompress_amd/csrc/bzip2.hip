@@ -35,10 +35,13 @@ constexpr int BZ_GROUP = 50;                   // symbols per selector (bzip2.li
 constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:217-219
 constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
 constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
+constexpr int BWT_THREADS = 512;               // bz_bwt_kernel: three workgroups fit a CU (49 KB of LDS each), so a
+constexpr int BWT_WAVES = BWT_THREADS / 64;    // 600-block batch is resident at once instead of in two rounds
 
 #ifdef SEMZ_STAMPS
 // diagnostic build only (make STAMPS=1): shader-clock totals of bz_decode_kernel summed over all blocks
 __device__ unsigned long long g_bz_stamps[16];
+__device__ unsigned long long g_bwt_stamps[8];
 #define BZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
 #define BZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define BZ_COUNT(i) (n_acc[i]++)
@@ -678,7 +681,7 @@ __device__ __forceinline__ uint32_t rle1_step(Rle1 &s, uint32_t b, uint32_t &out
     return b;
 }
 
-__global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *meta, const uint8_t *pre_all,
+__global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz_meta *meta, const uint8_t *pre_all,
                                                       uint32_t *tt_all, uint8_t *post_all, bz_seg *seg_all)
 {
     extern __shared__ __align__(16) uint32_t smem[];
@@ -692,19 +695,25 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
     bz_seg *segs = seg_all + (size_t)u * BZ_SEGS;
 
+#ifdef SEMZ_STAMPS
+    uint64_t w_last = __builtin_amdgcn_s_memtime();
+#define BWT_STAMP(i) do { if (tid == 0) { uint64_t t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_bwt_stamps[i], (unsigned long long)(t_now - w_last)); w_last = t_now; } } while (0)
+#else
+#define BWT_STAMP(i) do { } while (0)
+#endif
     // ---- 1. per-wave byte histograms ----
     uint32_t *hist = smem;                         // [16][256]
-    uint32_t *cumm = smem + 16 * 256;              // [256]
-    for (uint32_t i = tid; i < 16 * 256 + 256; i += 1024) smem[i] = 0;
+    uint32_t *cumm = smem + BWT_WAVES * 256;       // [256]
+    for (uint32_t i = tid; i < BWT_WAVES * 256 + 256; i += BWT_THREADS) smem[i] = 0;
     __syncthreads();
-    const uint32_t chunk = (((n + 15) / 16) + 63) & ~63u;
+    const uint32_t chunk = (((n + BWT_WAVES - 1) / BWT_WAVES) + 63) & ~63u;
     const uint32_t cbeg = wave * chunk, cend = cbeg + chunk < n ? cbeg + chunk : n;
     for (uint32_t i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + pre[i]], 1u);
     __syncthreads();
     // ---- 2. prefix sums: cumm[v] (bzip2.lisp:150-151) and each wave's base per byte value ----
     if (tid < 256) {
         uint32_t total = 0;
-        for (int w = 0; w < 16; w++) { uint32_t t = hist[w * 256 + tid]; hist[w * 256 + tid] = total; total += t; }
+        for (int w = 0; w < BWT_WAVES; w++) { uint32_t t = hist[w * 256 + tid]; hist[w * 256 + tid] = total; total += t; }
         cumm[tid] = total;
     }
     __syncthreads();
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
         for (int v = 0; v < 256; v++) { uint32_t t = cumm[v]; cumm[v] = acc; acc += t; }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < 16 * 256; i += 1024) hist[i] += cumm[i & 255];
+    for (uint32_t i = tid; i < BWT_WAVES * 256; i += BWT_THREADS) hist[i] += cumm[i & 255];
     __syncthreads();
     // ---- 3. stable scatter: tt[cumm[v]++] = (i << 8) | v  (bzip2.lisp:153-156) ----
     for (uint32_t b0 = cbeg; b0 < cend; b0 += 64) {
@@ -740,6 +749,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     __threadfence_block();
     __syncthreads();
 
+    BWT_STAMP(0);
     // ---- 4. inverse BWT walk (bzip2.lisp:158-163) as chain segments ----
     // out[j] = low byte of tt[k_j], k_0 = origPtr, k_{j+1} = tt[k_j] >> 8.
     // Markers: k = origPtr (id 0) and k = j*S (id j+1).  Every marker walks until it meets a marker.
@@ -752,14 +762,14 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     const uint32_t nreg = n ? (n + S - 1) / S : 0; // regular markers 0, S, 2S, ...
     const uint32_t nmark = nreg + 1;
     const uint32_t orig = m.orig;
-    for (uint32_t i = tid; i < nmark; i += 1024) seg_off[i] = 0xFFFFFFFFu;
+    for (uint32_t i = tid; i < nmark; i += BWT_THREADS) seg_off[i] = 0xFFFFFFFFu;
     if (n) {
-        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * 1024) {
+        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
             uint32_t k[4], len[4];
             bool act[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * 1024;
+                uint32_t id = id0 + c * BWT_THREADS;
                 act[c] = id < nmark;
                 k[c] = id == 0 ? orig : (id - 1) * S;
                 len[c] = 0;
@@ -779,7 +789,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * 1024;
+                uint32_t id = id0 + c * BWT_THREADS;
                 if (id < nmark) {
                     seg_len[id] = len[c];
                     seg_next[id] = k[c] == orig ? 0 : k[c] / S + 1;
@@ -788,6 +798,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
         }
     }
     __syncthreads();
+    BWT_STAMP(1);
     if (tid == 0) {
         uint32_t t = 0, off = 0;
         while (off < n && seg_off[t] == 0xFFFFFFFFu) {
@@ -798,16 +809,17 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
         misc[0] = off;                              // >= n, or the length of origPtr's cycle if shorter
     }
     __syncthreads();
+    BWT_STAMP(2);
     const uint32_t cyc = misc[0];
     const uint32_t wlim = cyc < n ? cyc : n;
     if (n) {
-        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * 1024) {
+        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
             uint32_t k[4], o[4], e[4];
             bool act[4];
             bool any = false;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * 1024;
+                uint32_t id = id0 + c * BWT_THREADS;
                 act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu;
                 k[c] = id == 0 ? orig : (id - 1) * S;
                 o[c] = act[c] ? seg_off[id] : 0;
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     __syncthreads();
     if (cyc < n) {
         // origPtr's cycle is shorter than the block: the output is periodic
-        for (uint32_t j = cyc + tid; j < n; j += 1024) post[j] = post[j % cyc];
+        for (uint32_t j = cyc + tid; j < n; j += BWT_THREADS) post[j] = post[j % cyc];
         __threadfence_block();
         __syncthreads();
     }
@@ -850,6 +862,7 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     __threadfence_block();
     __syncthreads();
 
+    BWT_STAMP(3);
     // ---- 6. RLE1 sizing: every thread parses its segment from each of the five
     //         possible entry classes; thread 0 then chains the real states ----
     // classes: 0 fresh (last != first byte, reps < 3), 1 count byte expected (reps == 3),
@@ -857,24 +870,40 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
     uint32_t *r_len = smem;                         // [BZ_SEGS][5]
     uint32_t *r_exit = smem + BZ_SEGS * 5;          // [BZ_SEGS][5]  (last+1) << 2 | reps
     const uint32_t seglen = (n + BZ_SEGS - 1) / BZ_SEGS;
-    const uint32_t sbeg = tid * seglen < n ? tid * seglen : n;
-    const uint32_t send = sbeg + seglen < n ? sbeg + seglen : n;
-    {
+    for (uint32_t sg = tid; sg < (uint32_t)BZ_SEGS; sg += BWT_THREADS) {
+        const uint32_t sbeg = sg * seglen < n ? sg * seglen : n;
+        const uint32_t send = sbeg + seglen < n ? sbeg + seglen : n;
         const int first = sbeg < send ? post[sbeg] : -1;
         Rle1 st[5] = {{-1, 0}, {first, 3}, {first, 0}, {first, 1}, {first, 2}};
         uint32_t ol[5] = {0, 0, 0, 0, 0};
-        for (uint32_t i = sbeg; i < send; i++) {
-            uint32_t b = post[i], ob;
+        // the segment, one whole 64-byte line at a time (see bz_rle1_kernel)
+        for (uint32_t line = sbeg & ~63u; line < send; line += 64) {
+            uint32_t w[16];
+            const uint4 *lp = reinterpret_cast<const uint4 *>(post + line);
 #pragma unroll
-            for (int c = 0; c < 5; c++) ol[c] += rle1_step(st[c], b, ob);
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = lp[q];
+                w[4 * q] = x.x; w[4 * q + 1] = x.y; w[4 * q + 2] = x.z; w[4 * q + 3] = x.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 64; j++) {
+                const uint32_t i = line + j;
+                if (i >= sbeg && i < send) {
+                    const uint32_t b = (w[j >> 2] >> (8 * (j & 3))) & 0xFF;
+                    uint32_t ob;
+#pragma unroll
+                    for (int c = 0; c < 5; c++) ol[c] += rle1_step(st[c], b, ob);
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            r_len[tid * 5 + c] = ol[c];
-            r_exit[tid * 5 + c] = ((uint32_t)(st[c].last + 1) << 2) | (uint32_t)st[c].reps;
+            r_len[sg * 5 + c] = ol[c];
+            r_exit[sg * 5 + c] = ((uint32_t)(st[c].last + 1) << 2) | (uint32_t)st[c].reps;
         }
     }
     __syncthreads();
+    BWT_STAMP(4);
     if (tid == 0) {
         Rle1 st = {-1, 0};
         uint64_t off = 0;
@@ -896,6 +925,8 @@ __global__ __launch_bounds__(1024) void bz_bwt_kernel(uint32_t nunits, bz_meta *
         }
         meta[u].out_len = off;
     }
+    BWT_STAMP(5);
+#undef BWT_STAMP
 }
 
 // Exclusive scan of the block sizes for SEMZ_OUT_AUTO units, capacity checks, results and tails.
@@ -1001,6 +1032,13 @@ __global__ __launch_bounds__(1024) void bz_rle1_kernel(uint32_t nunits, const bz
 extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
 {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bz_stamps), sizeof(g_bz_stamps)) != hipSuccess) return -1;
+    {
+        unsigned long long w[8];
+        if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_bwt_stamps), sizeof w) != hipSuccess) return -1;
+        printf("bz_bwt_kernel Mticks summed over blocks: hist+scatter %.1f  walk-measure %.1f  link %.1f  walk-write %.1f  rle1-size %.1f  rle1-chain %.1f\n",
+               w[0] / 1e6, w[1] / 1e6, w[2] / 1e6, w[3] / 1e6, w[4] / 1e6, w[5] / 1e6);
+        if (reset) { unsigned long long z8[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bwt_stamps), z8, sizeof z8); }
+    }
     if (reset) {
         unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_bz_stamps), z, sizeof z) != hipSuccess) return -1;
@@ -1031,7 +1069,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre);
     semz_span_end(c);
     semz_span_begin(c, "bz_bwt_kernel");
-    bz_bwt_kernel<<<nunits, 1024, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,
+    bz_bwt_kernel<<<nunits, BWT_THREADS, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,
                                                      (uint8_t *)post, (bz_seg *)segs);
     semz_span_end(c);
     semz_span_begin(c, "bz_offsets_kernel");
