@@ -449,6 +449,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             ensure_staged();
             if (state == ST_HUFF) {
                 if (dist_mode != MODE_LITONLY && endbits - P >= 64 + TOKEN_BITS) {
+                    bool careful = false;
+                    for (;;) {
                     // ---- window decode: lane l takes the token that would start at bit P + l ----
                     COUNT(0, 1);
                     const uint64_t bp = P + lane;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     uint32_t off = 0;
                     do {
                         const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tbits, (int)off);
-                        mask |= 1ull << off;
+                        asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(off));       // mask |= 1 << off, one instruction
                         off += t;
                     } while (off < 64);
                     const bool start = (mask >> lane) & 1;
@@ -503,7 +505,10 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                             rbytes += total;
                             ntok += nm;
                             P += off;
-                            continue;
+                            // straight on to the next window while the round, the staged input and the input's end allow
+                            if (ntok < (uint32_t)QCAP && rbytes < (uint32_t)ROUND_BYTES && endbits - P >= 64 + TOKEN_BITS &&
+                                (P >> 3) + 32 <= s_hi) continue;
+                            break;
                         }
                     }
                     const uint32_t have = avail + ooff;                        // deflate.lisp:329-331
@@ -514,7 +519,6 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const uint64_t cutmask = hardmask | __builtin_amdgcn_ballot_w64(soft);
                     uint64_t keep = mask;
                     uint32_t adv = off;
-                    bool careful = false;
                     if (cutmask) {
                         const uint32_t c = (uint32_t)__builtin_ctzll(cutmask);
                         keep = mask & ((1ull << c) - 1);
@@ -532,6 +536,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     ntok += (uint32_t)__builtin_popcountll(matchmask & keep);
                     COUNT(1, (uint32_t)__builtin_popcountll(keep));
                     P += adv;
+                    break;
+                    }
                     // the scalar step may queue a match and write a literal: only inside the round's limits
                     if (!careful || ntok >= (uint32_t)QCAP || rbytes >= (uint32_t)ROUND_BYTES) continue;
                     ensure_staged();
