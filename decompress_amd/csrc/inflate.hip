@@ -94,7 +94,7 @@ struct TreeMeta {
 
 struct __align__(16) UnitLds {
     uint8_t ring[RING];
-    uint8_t inring[IN_RING];
+    uint8_t inring[IN_RING + 16];        // the first 16 bytes again behind the end: a window never wraps
     uint2 queue[QCAP];
     uint16_t lit_root[1 << LIT_ROOT_BITS];
     uint16_t dist_root[1 << DIST_ROOT_BITS];
@@ -147,6 +147,10 @@ __device__ __forceinline__ uint32_t dist_entry(uint32_t code, uint32_t len)
     return (code << 11) | (hi << 8) | (extra << 4) | len;
 }
 __device__ __forceinline__ uint32_t clen_entry(uint32_t sym, uint32_t len) { return (sym << 3) | len; }
+// Root tables hold 0 ("ask the scalar step") for everything the window decode does not take itself: end of
+// block, 286/287 and distance codes 30/31, besides the codes longer than the root index.
+__device__ __forceinline__ uint32_t lit_root_entry(uint32_t sym, uint32_t len) { return sym == 256 || sym > 285 ? 0u : lit_entry(sym, len); }
+__device__ __forceinline__ uint32_t dist_root_entry(uint32_t code, uint32_t len) { return code > 29 ? 0u : dist_entry(code, len); }
 
 // Canonical decode of a left-aligned 15-bit MSB-first window, lengths lo..hi.
 // Returns the code length (0 if none in range) and the symbol's index in sorted[].
@@ -414,7 +418,10 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             x.y &= (uint32_t)(keep >> 32);
         }
         lds_sync();
-        *reinterpret_cast<uint2 *>(L.inring + ((uint32_t)v & (IN_RING - 1))) = x;
+        const uint32_t ro = (uint32_t)v & (IN_RING - 1);
+        *reinterpret_cast<uint2 *>(L.inring + ro) = x;
+        if (ro < 16) *reinterpret_cast<uint2 *>(L.inring + IN_RING + ro) = x;
+        join_lanes();
         lds_sync();
         s_hi += IN_PIECE;
     };
@@ -427,7 +434,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
     // 32 bits at bit position q, scalar (block headers, code lengths, the careful token step)
     auto rd32 = [&](uint64_t q) -> uint32_t {
         const uint32_t d = (uint32_t)(q >> 5);
-        const uint32_t w0 = uni(ring32[d & (IN_RING / 4 - 1)]), w1 = uni(ring32[(d + 1) & (IN_RING / 4 - 1)]);
+        const uint32_t *wp = ring32 + (d & (IN_RING / 4 - 1));
+        const uint32_t w0 = uni(wp[0]), w1 = uni(wp[1]);
         return (uint32_t)((((uint64_t)w1 << 32) | w0) >> (q & 31));
     };
     auto short_of = [&](uint32_t n) -> bool { return endbits - P < (uint64_t)n; };
@@ -450,28 +458,30 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             if (state == ST_HUFF) {
                 if (dist_mode != MODE_LITONLY && endbits - P >= 64 + TOKEN_BITS) {
                     bool careful = false;
+                    // 32-bit stand-ins for the loop conditions: bits to the end of the input (saturated), staged bits ahead
+                    uint32_t left = (uint32_t)(endbits - P < 0x7FFFFFFFull ? endbits - P : 0x7FFFFFFFull);
+                    uint32_t sleft = (uint32_t)(8 * s_hi - P);
+                    const bool round_ok = room >= (uint32_t)ROUND_BYTES && wsize >= 32768u;
                     for (;;) {
                     // ---- window decode: lane l takes the token that would start at bit P + l ----
                     COUNT(0, 1);
-                    const uint64_t bp = P + lane;
-                    const uint32_t d = (uint32_t)(bp >> 5), sh = (uint32_t)bp & 31;
-                    const uint32_t w0 = ring32[d & (IN_RING / 4 - 1)], w1 = ring32[(d + 1) & (IN_RING / 4 - 1)],
-                                   w2 = ring32[(d + 2) & (IN_RING / 4 - 1)];
+                    const uint32_t bp = (uint32_t)P + lane;                    // the ring index only needs the low bits
+                    const uint32_t sh = bp & 31;
+                    const uint32_t *wp = ring32 + ((bp >> 5) & (IN_RING / 4 - 1));
+                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
                     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
                     const uint32_t e = L.lit_root[lo & ((1u << LIT_ROOT_BITS) - 1)];
                     const uint32_t cl = e & 15;
                     const bool islit = (e & LIT_FLAG) != 0;
-                    const uint32_t lx0 = (e >> 5) & 7;
-                    const bool special = !islit && lx0 == 7;                   // end of block, 286/287
-                    const uint32_t lx = (islit || special) ? 0u : lx0;
+                    const uint32_t lx = (e >> 5) & 7;                          // 0 in literal entries
                     const uint32_t length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(lo, cl, lx);
                     const uint32_t o2 = cl + lx;                               // <= 20
                     const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, o2);
                     const uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
                     const uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
                     const uint32_t distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
-                    // tokens the scalar step has to look at: long codes, block end, invalid codes
-                    bool stop = cl == 0 || special || (!islit && (dl == 0 || (dd & DIST_BAD)));
+                    // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
+                    const bool stop = cl == 0 || (!islit && dl == 0);
                     const uint32_t tbits = stop ? 64u : (islit ? cl : o2 + dl + dx);
                     const uint32_t olen = stop ? 0u : (islit ? 1u : length);
                     // the chain of token starts inside the window
@@ -493,8 +503,9 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                         // the usual window: no token for the scalar step, everything fits the round: keep it whole
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         const uint32_t nm = (uint32_t)__builtin_popcountll(matchmask);
-                        bool whole = (__builtin_amdgcn_ballot_w64(stop) & mask) == 0 && rbytes + total <= (uint32_t)ROUND_BYTES &&
-                                     ntok + nm <= (uint32_t)QCAP && room >= (uint32_t)ROUND_BYTES && wsize >= 32768u;
+                        // (all operands are far below 2^31: one sign test for both limits)
+                        bool whole = (__builtin_amdgcn_ballot_w64(stop) & mask) == 0 && round_ok &&
+                                     (int32_t)(((uint32_t)ROUND_BYTES - (rbytes + total)) | ((uint32_t)QCAP - (ntok + nm))) >= 0;
                         if (whole && avail < 32768u) whole = __builtin_amdgcn_ballot_w64(ismatch && distance > avail + ooff) == 0;
                         if (whole) {
                             if (start && islit) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
@@ -505,9 +516,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                             rbytes += total;
                             ntok += nm;
                             P += off;
+                            left -= off;
+                            sleft -= off;
                             // straight on to the next window while the round, the staged input and the input's end allow
-                            if (ntok < (uint32_t)QCAP && rbytes < (uint32_t)ROUND_BYTES && endbits - P >= 64 + TOKEN_BITS &&
-                                (P >> 3) + 32 <= s_hi) continue;
+                            if ((int32_t)(((uint32_t)QCAP - 1 - ntok) | ((uint32_t)ROUND_BYTES - 1 - rbytes) |
+                                          (left - (64 + TOKEN_BITS)) | (sleft - 256)) >= 0) continue;
                             break;
                         }
                     }
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     uint32_t cl = e & 15;
                     if (cl == 0) {
                         uint32_t v15 = __brev(x) >> 17, idx = 0;
-                        cl = canon_find(L.lit, v15, LIT_ROOT_BITS + 1, 15, idx);
+                        cl = canon_find(L.lit, v15, 1, 15, idx);
                         e = lit_entry(uni((uint32_t)L.lit_sorted[idx]), cl);
                     }
                     if (short_of(lit_full ? (uint32_t)lit_max : cl)) FAIL(SEMZ_EOF, 0)
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     uint32_t dl = dd & 15;
                     if (dl == 0) {
                         uint32_t v15 = __brev(x) >> 17, idx = 0;
-                        dl = canon_find(L.dist, v15, DIST_ROOT_BITS + 1, 15, idx);
+                        dl = canon_find(L.dist, v15, 1, 15, idx);
                         dd = dist_entry(uni((uint32_t)L.dist_sorted[idx]), dl);
                     }
                     if (short_of(dist_full ? (uint32_t)dist_max : dl)) FAIL(SEMZ_EOF, 0)
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
             }
             lds_sync();
             if (st.code == SEMZ_OK) {
-                build_tree<LIT_ROOT_BITS>(L.lens, nlit, L.lit, L.lit_sorted, L.lit_root, lit_entry);
+                build_tree<LIT_ROOT_BITS>(L.lens, nlit, L.lit, L.lit_sorted, L.lit_root, lit_root_entry);
                 const int lstatus = (int)uni(L.lit.status);
                 if (lstatus != SEMZ_OK) st.set(lstatus, 0);
                 else {
@@ -901,9 +914,9 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                             L.lens[lane] = v;
                         }
                         lds_sync();
-                        build_tree<DIST_ROOT_BITS>(L.lens, 32, L.dist, L.dist_sorted, L.dist_root, dist_entry);
+                        build_tree<DIST_ROOT_BITS>(L.lens, 32, L.dist, L.dist_sorted, L.dist_root, dist_root_entry);
                     } else {
-                        build_tree<DIST_ROOT_BITS>(dlens, ndist, L.dist, L.dist_sorted, L.dist_root, dist_entry);
+                        build_tree<DIST_ROOT_BITS>(dlens, ndist, L.dist, L.dist_sorted, L.dist_root, dist_root_entry);
                     }
                     const int dstatus = (int)uni(L.dist.status);
                     if (dstatus != SEMZ_OK) st.set(dstatus, 0);
