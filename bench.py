@@ -150,6 +150,10 @@ def main():
     ap.add_argument("--unit-bytes", type=int, default=0)
     ap.add_argument("--check", default="crc64", choices=["crc64", "sha256", "crc32", "none"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="corpus generation processes (default: the CPU share); 1 = no child processes at all, "
+                         "which is what a run under rocprofv3 --pmc wants: pool workers forked under the profiler "
+                         "inherit its SIGTERM handler and can hang when the pool is torn down")
     ap.add_argument("--replicate", type=int, default=0,
                     help="bzip2/xz: decode every generated stream this many times over (bounds corpus generation time)")
     a = ap.parse_args()
@@ -180,7 +184,7 @@ def main():
 
     from decompress_amd import _lib
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(16, ncpu // max(1, world)))
+    workers = a.workers or max(1, min(16, ncpu // max(1, world)))
     t_gen = time.perf_counter()
     W = build_workload(a.format, nunits, unit_bytes, 0x5EED0001 + rank * 1000003, workers, a.check, rep)
     t_gen = time.perf_counter() - t_gen
