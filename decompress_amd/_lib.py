@@ -45,6 +45,7 @@ UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2 
 FMT_DEFLATE, FMT_ZLIB, FMT_GZIP, FMT_BZIP2, FMT_RAW_LZMA, FMT_LZMA, FMT_RAW_LZMA2, FMT_LZMA2, FMT_XZ = range(9)
 UF_HAVE_DICT_FN, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE = 1, 4, 8
 FILTER_DELTA, FILTER_X86 = 1, 2
+FILTER_POWERPC, FILTER_IA64, FILTER_ARM, FILTER_ARMTHUMB, FILTER_SPARC, FILTER_ARM64 = 3, 4, 5, 6, 7, 8
 CHECK_NONE, CHECK_CRC32, CHECK_CRC64, CHECK_SHA256 = 0, 1, 4, 10
 
 OUT_AUTO = 0xFFFFFFFFFFFFFFFF

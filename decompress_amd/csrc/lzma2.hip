@@ -7,6 +7,7 @@
 //   LZMA2 control-byte state machine     lzma2.lisp:77-204
 //   xz block end (sizes, padding, check) xz.lisp:426-457
 //   x86 BCJ filter                       xz-bcj-filters.lisp:169-219
+//   ARM/ARM64/Thumb/IA-64/PowerPC/SPARC  xz-bcj-filters.lisp:45-167
 //   delta filter                         xz.lisp:238-258
 //
 // lzma2_kernel: one unit per 64-lane wavefront (one wavefront per workgroup).
@@ -20,7 +21,7 @@
 // through L2.  The block's own output span is the dictionary: every xz block
 // starts with a dictionary reset (lzma2.lisp:97-98).
 //
-// bcj_x86_kernel / delta_kernel: the block's filter chain, applied in place in
+// bcj_x86_kernel / bcj_simple_kernel / delta_kernel: the block's filter chain, applied in place in
 // HBM after LZMA2, then checksums.hip computes and compares the block check.
 #include "semz_host.h"
 
@@ -611,6 +612,97 @@ __global__ __launch_bounds__(64) void delta_kernel(const semz_unit *units, uint3
     }
 }
 
+// ---- the other BCJ inverses in place (xz-bcj-filters.lisp:45-167), one 256-thread workgroup per unit ----
+// These filters look at fixed positions (every 4th byte, every 2nd for ARM-Thumb, every 16th for IA-64),
+// counted from the start of the block, and no conversion changes the bytes another position tests: an
+// ARM-Thumb BL pair at i has (b[i+1] & 0xF8) == 0xF0 and (b[i+3] & 0xF8) == 0xF8 before and after, which
+// rules out a pair at i - 2 and at i + 2 (the reference's "skip two more bytes" never skips a candidate).
+// So every position is converted independently.  Blocks start at arbitrary addresses: byte accesses.
+__global__ __launch_bounds__(256) void bcj_simple_kernel(const semz_unit *units, uint32_t nunits, uint8_t *out,
+                                                         const semz_result *results, int stage)
+{
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const semz_unit un = units[u];
+    const semz_result r = results[u];
+    const uint32_t f = (un.filters >> (4 * stage)) & 15;
+    if (r.status != SEMZ_OK || f < SEMZ_FILTER_POWERPC || f > SEMZ_FILTER_ARM64) return;
+    uint8_t *b = out + r.out_off;
+    const uint64_t n = r.out_len;
+    const uint32_t now_pos = un.param2;
+    const uint64_t step = f == SEMZ_FILTER_IA64 ? 16 : f == SEMZ_FILTER_ARMTHUMB ? 2 : 4;
+    const uint64_t need = f == SEMZ_FILTER_IA64 ? 16 : 4;
+    for (uint64_t i = step * threadIdx.x; i + need <= n; i += step * 256) {
+        const uint32_t pc = now_pos + (uint32_t)i;
+        if (f == SEMZ_FILTER_ARM) {
+            if (b[i + 3] == 0xEB) {
+                const uint32_t v = ((((uint32_t)b[i] | ((uint32_t)b[i + 1] << 8) | ((uint32_t)b[i + 2] << 16)) << 2) - (pc + 8)) >> 2;
+                b[i] = (uint8_t)v; b[i + 1] = (uint8_t)(v >> 8); b[i + 2] = (uint8_t)(v >> 16);
+            }
+        } else if (f == SEMZ_FILTER_ARM64) {
+            const uint32_t instr = (uint32_t)b[i] | ((uint32_t)b[i + 1] << 8) | ((uint32_t)b[i + 2] << 16) | ((uint32_t)b[i + 3] << 24);
+            uint32_t v = instr;
+            if ((instr >> 26) == 0x25) v = ((instr - (pc >> 2)) & 0x03FFFFFFu) | 0x94000000u;
+            else if ((instr & 0x9F000000u) == 0x90000000u) {
+                const uint32_t src = ((instr >> 29) & 3) | ((instr >> 3) & 0x001FFFFCu);
+                if (((src + 0x00020000u) & 0x001C0000u) == 0) {
+                    const uint32_t dest = src - (pc >> 12);
+                    v = (instr & 0x9000001Fu) | ((dest & 3) << 29) | ((dest & 0x0003FFFCu) << 3) | ((0u - (dest & 0x00020000u)) & 0x00E00000u);
+                }
+            }
+            if (v != instr) { b[i] = (uint8_t)v; b[i + 1] = (uint8_t)(v >> 8); b[i + 2] = (uint8_t)(v >> 16); b[i + 3] = (uint8_t)(v >> 24); }
+        } else if (f == SEMZ_FILTER_ARMTHUMB) {
+            if ((b[i + 1] & 0xF8) == 0xF0 && (b[i + 3] & 0xF8) == 0xF8) {
+                const uint32_t src = ((((uint32_t)b[i + 1] & 7) << 19) | ((uint32_t)b[i] << 11) | (((uint32_t)b[i + 3] & 7) << 8) | (uint32_t)b[i + 2]) << 1;
+                const uint32_t dest = (src - (pc + 4)) >> 1;
+                b[i + 1] = (uint8_t)(0xF0 | ((dest >> 19) & 7));
+                b[i] = (uint8_t)(dest >> 11);
+                b[i + 3] = (uint8_t)(0xF8 | ((dest >> 8) & 7));
+                b[i + 2] = (uint8_t)dest;
+            }
+        } else if (f == SEMZ_FILTER_POWERPC) {
+            if ((b[i] >> 2) == 0x12 && (b[i + 3] & 3) == 1) {
+                const uint32_t src = (((uint32_t)b[i] & 3) << 24) | ((uint32_t)b[i + 1] << 16) | ((uint32_t)b[i + 2] << 8) | ((uint32_t)b[i + 3] & ~3u);
+                const uint32_t dest = src - pc;
+                b[i] = (uint8_t)(0x48 | ((dest >> 24) & 3));
+                b[i + 1] = (uint8_t)(dest >> 16);
+                b[i + 2] = (uint8_t)(dest >> 8);
+                b[i + 3] = (uint8_t)((b[i + 3] & 3) | (dest & 0xFF));
+            }
+        } else if (f == SEMZ_FILTER_SPARC) {
+            if ((b[i] == 0x40 && (b[i + 1] & 0xC0) == 0x00) || (b[i] == 0x7F && (b[i + 1] & 0xC0) == 0xC0)) {
+                const uint32_t src = ((uint32_t)b[i] << 24) | ((uint32_t)b[i + 1] << 16) | ((uint32_t)b[i + 2] << 8) | b[i + 3];
+                const uint32_t dest = ((src << 2) - pc) >> 2;
+                const uint32_t v = (((0u - ((dest >> 22) & 1)) << 22) & 0x3FFFFFFFu) | (dest & 0x3FFFFFu) | 0x40000000u;
+                b[i] = (uint8_t)(v >> 24); b[i + 1] = (uint8_t)(v >> 16); b[i + 2] = (uint8_t)(v >> 8); b[i + 3] = (uint8_t)v;
+            }
+        } else {                                                   // IA-64: three 41-bit slots per 16-byte bundle
+            const uint32_t tmpl = b[i] & 0x1F;
+            // masks 16..31: 4 4 6 6 0 0 7 7 4 4 0 0 4 4 0 0 (three bits each), templates below 16 have none
+            const uint64_t table = 0x0ull | (4ull << 0) | (4ull << 3) | (6ull << 6) | (6ull << 9) | (7ull << 18) | (7ull << 21) |
+                                   (4ull << 24) | (4ull << 27) | (4ull << 36) | (4ull << 39);
+            const uint32_t mask = tmpl < 16 ? 0u : (uint32_t)(table >> (3 * (tmpl - 16))) & 7;
+            uint32_t bit_pos = 5;
+            for (uint32_t slot = 0; slot < 3; slot++, bit_pos += 41) {
+                if (!((mask >> slot) & 1)) continue;
+                const uint64_t byte_pos = bit_pos >> 3;
+                const uint32_t bit_res = bit_pos & 7;
+                uint64_t instruction = 0;
+                for (int k = 0; k < 6; k++) instruction |= (uint64_t)b[i + byte_pos + k] << (8 * k);
+                const uint64_t inst_norm = instruction >> bit_res;
+                if (((inst_norm >> 37) & 0xF) == 0x5 && ((inst_norm >> 9) & 0x7) == 0) {
+                    const uint32_t src = (uint32_t)(((inst_norm >> 13) & 0xFFFFF) | (((inst_norm >> 36) & 1) << 20)) << 4;
+                    const uint32_t dest = (src - pc) >> 4;
+                    uint64_t v = (((uint64_t)1 << bit_res) - 1) & instruction;
+                    v |= ((((uint64_t)(dest & 0x100000)) << (36 - 20)) | ((uint64_t)(dest & 0xFFFFF) << 13) |
+                          (inst_norm & ~((uint64_t)0x8FFFFF << 13))) << bit_res;
+                    for (int k = 0; k < 6; k++) b[i + byte_pos + k] = (uint8_t)(v >> (8 * k));
+                }
+            }
+        }
+    }
+}
+
 } // namespace
 
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
@@ -625,6 +717,7 @@ int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     semz_span_begin(c, "xz_filter_kernels");
     for (int stage = 0; stage < 3; stage++) {
         bcj_x86_kernel<<<nunits, 64, 0, c->stream>>>(d_units, nunits, d_out, d_results, stage);
+        bcj_simple_kernel<<<nunits, 256, 0, c->stream>>>(d_units, nunits, d_out, d_results, stage);
         delta_kernel<<<nunits, 64, 0, c->stream>>>(d_units, nunits, d_out, d_results, stage);
     }
     semz_span_end(c);

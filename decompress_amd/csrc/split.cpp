@@ -236,11 +236,14 @@ XzBlockHeader parse_xz_block_header(const uint8_t *in, uint64_t pos, uint64_t in
             if (pl == 4) off = (uint32_t)pp[0] | ((uint32_t)pp[1] << 8) | ((uint32_t)pp[2] << 16) | ((uint32_t)pp[3] << 24);
             else if (pl != 0) return fail(SEMZ_E_XZ_BCJ_PROPS, (uint32_t)pl);
             if (off % align[id - 4]) return fail(SEMZ_E_XZ_BCJ_ALIGN, off);
-            // only x86 is on the hot path; a second x86 stage with another offset is not representable
-            if (id != 0x04 || (have_bcj && off != h.bcj_offset)) return fail(SEMZ_E_UNSUPPORTED, (uint32_t)id);
+            // semz_unit has one start offset: a second BCJ stage with another offset is not representable
+            if (have_bcj && off != h.bcj_offset) return fail(SEMZ_E_UNSUPPORTED, (uint32_t)id);
             have_bcj = true;
             h.bcj_offset = off;
-            h.filters |= (uint32_t)SEMZ_FILTER_X86 << (4 * stage++);
+            // xz ids 0x04 x86, 0x05 PowerPC, 0x06 IA-64, 0x07 ARM, 0x08 ARM-Thumb, 0x09 SPARC, 0x0A ARM64 (xz.lisp:333-339)
+            static const uint8_t code[7] = {SEMZ_FILTER_X86, SEMZ_FILTER_POWERPC, SEMZ_FILTER_IA64, SEMZ_FILTER_ARM,
+                                            SEMZ_FILTER_ARMTHUMB, SEMZ_FILTER_SPARC, SEMZ_FILTER_ARM64};
+            h.filters |= (uint32_t)code[id - 4] << (4 * stage++);
         } else if (id == 0x21) {
             if (idx != nfilters) return fail(SEMZ_E_XZ_LZMA2_NOT_LAST, 0);
             if (pl != 1) return fail(SEMZ_E_XZ_LZMA2_PROPS, (uint32_t)pl);

@@ -63,7 +63,10 @@ enum {
 };
 
 /* xz filters that follow LZMA2 when decoding (semz_unit.filters, xz.lisp:311-344) */
-enum { SEMZ_FILTER_END = 0, SEMZ_FILTER_DELTA = 1, SEMZ_FILTER_X86 = 2 };
+enum { SEMZ_FILTER_END = 0, SEMZ_FILTER_DELTA = 1, SEMZ_FILTER_X86 = 2,
+       /* the other branch/call/jump filters, xz-bcj-filters.lisp:45-167 */
+       SEMZ_FILTER_POWERPC = 3, SEMZ_FILTER_IA64 = 4, SEMZ_FILTER_ARM = 5, SEMZ_FILTER_ARMTHUMB = 6,
+       SEMZ_FILTER_SPARC = 7, SEMZ_FILTER_ARM64 = 8 };
 
 /* xz check types (xz.lisp:12-31) */
 enum { SEMZ_CHECK_NONE = 0, SEMZ_CHECK_CRC32 = 1, SEMZ_CHECK_CRC64 = 4, SEMZ_CHECK_SHA256 = 10 };
@@ -87,7 +90,7 @@ typedef struct semz_unit {
     uint32_t in_bit_off;  /* bzip2: bit offset 0..7 (MSB-first) of the magic inside byte in_off */
     uint32_t param0;      /* deflate: window size (0 = 32768); bzip2: level 1..9; lzma2/xz: dictionary size */
     uint32_t param1;      /* xz: check type */
-    uint32_t param2;      /* xz: x86 BCJ start offset (xz.lisp:326-331) */
+    uint32_t param2;      /* xz: BCJ start offset (xz.lisp:326-331), shared by the BCJ stages of the chain */
     uint32_t param3;      /* xz: delta distances minus one, 8 bits per delta stage in chain order */
     uint32_t filters;     /* xz: filter chain applied to the LZMA2 output, 4 bits per stage
                              (SEMZ_FILTER_*), first applied stage in bits 3:0; in the block header

@@ -96,6 +96,7 @@ void orc_lzma2(const uint8_t *in, size_t in_len, int have_limit, uint64_t limit,
                uint32_t dict_size, uint8_t *out, size_t out_cap, orc_result *res);
 /* x86 BCJ inverse in place over a whole block (xz-bcj-filters.lisp:169-219). */
 void orc_bcj_x86(uint8_t *buf, size_t n, uint32_t start_offset);
+void orc_bcj_simple(uint8_t *buf, size_t n, uint32_t start_offset, unsigned filter_id);   /* 0x05 .. 0x0A */
 /* XZ delta filter inverse in place (xz.lisp:238-258). */
 void orc_delta(uint8_t *buf, size_t n, unsigned distance);
 /* One xz member (stream header .. footer). res->detail = check type. */

@@ -61,6 +61,7 @@ def lib():
         _lib.orc_lzma2.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.c_char_p,
                                    C.c_size_t, C.POINTER(OResult)]
         _lib.orc_bcj_x86.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        _lib.orc_bcj_simple.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint]
         _lib.orc_delta.argtypes = [C.c_char_p, C.c_size_t, C.c_uint]
         _lib.orc_xz_member.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(OResult)]
         _lib.orc_decompress.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_char_p,
@@ -123,6 +124,13 @@ def lzma2(data, dict_size, limit=None, cap=1 << 22):
 def bcj_x86(buf, start=0):
     b = C.create_string_buffer(bytes(buf), len(buf))
     lib().orc_bcj_x86(b, len(buf), start)
+    return b.raw[:len(buf)]
+
+
+def bcj_simple(buf, filter_id, start=0):
+    """Inverse of the xz BCJ filter with id 0x05 (PowerPC) .. 0x0A (ARM64) over the whole buffer."""
+    b = C.create_string_buffer(bytes(buf), len(buf))
+    lib().orc_bcj_simple(b, len(buf), start, filter_id)
     return b.raw[:len(buf)]
 
 

@@ -1,5 +1,5 @@
 /*
- * xz.c -- oracle restatement of xz.lisp and xz-bcj-filters.lisp (x86) plus
+ * xz.c -- oracle restatement of xz.lisp and xz-bcj-filters.lisp plus
  * the delta filter.  TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
  *   stream header                 xz.lisp:78-112
@@ -10,6 +10,7 @@
  *   padding / next member         xz.lisp:118-134
  *   delta filter                  xz.lisp:238-258
  *   x86 BCJ                       xz-bcj-filters.lisp:169-219 (+ wrapper 14-43)
+ *   ARM, ARM64, ARM-Thumb, IA-64, PowerPC, SPARC BCJ   xz-bcj-filters.lisp:45-167
  *
  * The reference streams filters over 8 KiB buffers; both filters here are
  * applied once over the whole block, which gives the same bytes: the delta
@@ -59,6 +60,93 @@ void orc_bcj_x86(uint8_t *buf, size_t n, uint32_t start_offset)
             prev_mask |= 1;
             if (b == 0x00 || b == 0xFF) prev_mask |= 0x10;
         }
+    }
+}
+
+/* ---- the other BCJ inverses (xz-bcj-filters.lisp:45-167), whole buffer ----
+ * id: xz filter id 0x05 PowerPC, 0x06 IA-64, 0x07 ARM, 0x08 ARM-Thumb, 0x09 SPARC, 0x0A ARM64.
+ * The reference runs them over 8 KiB buffers and carries the bytes it cannot process yet
+ * over to the next call, with i counted from the start of the data: one pass over the whole
+ * block visits the same positions with the same now-pos + i. */
+static uint32_t ld24le(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16); }
+static uint32_t ld32le(const uint8_t *p) { return ld24le(p) | ((uint32_t)p[3] << 24); }
+static void st32le(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+
+void orc_bcj_simple(uint8_t *buf, size_t n, uint32_t now_pos, unsigned id)
+{
+    size_t i = 0;
+    if (id == 0x07) {                                               /* arm, :45-53 */
+        for (; i + 4 <= n; i += 4)
+            if (buf[i + 3] == 0xEB) {
+                uint32_t v = ((ld24le(buf + i) << 2) - (now_pos + (uint32_t)i + 8)) >> 2;
+                buf[i] = (uint8_t)v; buf[i + 1] = (uint8_t)(v >> 8); buf[i + 2] = (uint8_t)(v >> 16);
+            }
+    } else if (id == 0x0A) {                                        /* arm64, :55-80 */
+        for (; i + 4 <= n; i += 4) {
+            uint32_t pc = now_pos + (uint32_t)i, instr = ld32le(buf + i);
+            if ((instr >> 26) == 0x25) {
+                st32le(buf + i, ((instr - (pc >> 2)) & 0x03FFFFFFu) | 0x94000000u);
+            } else if ((instr & 0x9F000000u) == 0x90000000u) {
+                uint32_t src = ((instr >> 29) & 3) | ((instr >> 3) & 0x001FFFFCu);
+                if (((src + 0x00020000u) & 0x001C0000u) == 0) {
+                    uint32_t dest = src - (pc >> 12);
+                    st32le(buf + i, (instr & 0x9000001Fu) | ((dest & 3) << 29) | ((dest & 0x0003FFFCu) << 3) |
+                                    ((0u - (dest & 0x00020000u)) & 0x00E00000u));
+                }
+            }
+        }
+    } else if (id == 0x08) {                                        /* armthumb, :82-99 */
+        for (; i + 4 <= n; i += 2)
+            if ((buf[i + 1] & 0xF8) == 0xF0 && (buf[i + 3] & 0xF8) == 0xF8) {
+                uint32_t src = ((((uint32_t)buf[i + 1] & 7) << 19) | ((uint32_t)buf[i] << 11) |
+                                (((uint32_t)buf[i + 3] & 7) << 8) | (uint32_t)buf[i + 2]) << 1;
+                uint32_t dest = (src - (now_pos + (uint32_t)i + 4)) >> 1;
+                buf[i + 1] = (uint8_t)(0xF0 | ((dest >> 19) & 7));
+                buf[i] = (uint8_t)(dest >> 11);
+                buf[i + 3] = (uint8_t)(0xF8 | ((dest >> 8) & 7));
+                buf[i + 2] = (uint8_t)dest;
+                i += 2;
+            }
+    } else if (id == 0x06) {                                        /* ia64, :101-130 */
+        static const uint8_t masks[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 4, 4, 6, 6, 0, 0, 7, 7, 4, 4, 0, 0, 4, 4, 0, 0};
+        for (; i + 16 <= n; i += 16) {
+            unsigned mask = masks[buf[i] & 0x1F];
+            for (unsigned slot = 0, bit_pos = 5; slot < 3; slot++, bit_pos += 41) {
+                if (!((mask >> slot) & 1)) continue;
+                size_t byte_pos = bit_pos >> 3;
+                unsigned bit_res = bit_pos & 7;
+                uint64_t instruction = 0;
+                for (int k = 0; k < 6; k++) instruction |= (uint64_t)buf[i + byte_pos + k] << (8 * k);
+                uint64_t inst_norm = instruction >> bit_res;
+                if (((inst_norm >> 37) & 0xF) == 0x5 && ((inst_norm >> 9) & 0x7) == 0) {
+                    uint32_t src = (uint32_t)(((inst_norm >> 13) & 0xFFFFF) | (((inst_norm >> 36) & 1) << 20)) << 4;
+                    uint32_t dest = (src - (now_pos + (uint32_t)i)) >> 4;
+                    uint64_t v = (((uint64_t)1 << bit_res) - 1) & instruction;
+                    v |= ((((uint64_t)(dest & 0x100000)) << (36 - 20)) | ((uint64_t)(dest & 0xFFFFF) << 13) |
+                          (inst_norm & ~((uint64_t)0x8FFFFF << 13))) << bit_res;
+                    for (int k = 0; k < 6; k++) buf[i + byte_pos + k] = (uint8_t)(v >> (8 * k));
+                }
+            }
+        }
+    } else if (id == 0x05) {                                        /* powerpc, :132-148 */
+        for (; i + 4 <= n; i += 4)
+            if ((buf[i] >> 2) == 0x12 && (buf[i + 3] & 3) == 1) {
+                uint32_t src = (((uint32_t)buf[i] & 3) << 24) | ((uint32_t)buf[i + 1] << 16) | ((uint32_t)buf[i + 2] << 8) |
+                               ((uint32_t)buf[i + 3] & ~3u);
+                uint32_t dest = src - (now_pos + (uint32_t)i);
+                buf[i] = (uint8_t)(0x48 | ((dest >> 24) & 3));
+                buf[i + 1] = (uint8_t)(dest >> 16);
+                buf[i + 2] = (uint8_t)(dest >> 8);
+                buf[i + 3] = (uint8_t)((buf[i + 3] & 3) | (dest & 0xFF));
+            }
+    } else if (id == 0x09) {                                        /* sparc, :150-167 */
+        for (; i + 4 <= n; i += 4)
+            if ((buf[i] == 0x40 && (buf[i + 1] & 0xC0) == 0x00) || (buf[i] == 0x7F && (buf[i + 1] & 0xC0) == 0xC0)) {
+                uint32_t src = ((uint32_t)buf[i] << 24) | ((uint32_t)buf[i + 1] << 16) | ((uint32_t)buf[i + 2] << 8) | buf[i + 3];
+                uint32_t dest = ((src << 2) - (now_pos + (uint32_t)i)) >> 2;
+                uint32_t v = (((0u - ((dest >> 22) & 1)) << 22) & 0x3FFFFFFFu) | (dest & 0x3FFFFFu) | 0x40000000u;
+                buf[i] = (uint8_t)(v >> 24); buf[i + 1] = (uint8_t)(v >> 16); buf[i + 2] = (uint8_t)(v >> 8); buf[i + 3] = (uint8_t)v;
+            }
     }
 }
 
@@ -157,7 +245,6 @@ static void xz_block(orc_ctx *c, osrc *s, const uint8_t *hdr, size_t hlen, unsig
             else if (pl == 4) bcj_off = (uint32_t)pp[0] | ((uint32_t)pp[1] << 8) | ((uint32_t)pp[2] << 16) | ((uint32_t)pp[3] << 24);
             else orc_die(c, SEMZ_E_XZ_BCJ_PROPS, (uint32_t)pl);
             if (bcj_off % align[id - 4]) orc_die(c, SEMZ_E_XZ_BCJ_ALIGN, bcj_off);
-            if (id != 0x04) orc_die(c, SEMZ_E_UNSUPPORTED, (uint32_t)id);   /* non-x86 BCJ: "next" row, SURVEY 8f */
         } else if (id == 0x21) {
             if (idx != nfilters) orc_die(c, SEMZ_E_XZ_LZMA2_NOT_LAST, 0);
             if (pl != 1) orc_die(c, SEMZ_E_XZ_LZMA2_PROPS, (uint32_t)pl);
@@ -181,7 +268,8 @@ static void xz_block(orc_ctx *c, osrc *s, const uint8_t *hdr, size_t hlen, unsig
         else {
             uint32_t off = fplen[idx - 1] == 4 ? ((uint32_t)fprops[idx - 1][0] | ((uint32_t)fprops[idx - 1][1] << 8) |
                                                   ((uint32_t)fprops[idx - 1][2] << 16) | ((uint32_t)fprops[idx - 1][3] << 24)) : 0;
-            orc_bcj_x86(out + start, *pos - start, off);
+            if (fid[idx - 1] == 0x04) orc_bcj_x86(out + start, *pos - start, off);
+            else orc_bcj_simple(out + start, *pos - start, off, (unsigned)fid[idx - 1]);
         }
     }
     /* :block-end (xz.lisp:426-457) */

@@ -144,3 +144,27 @@ def test_corrupt_xz_blocks(engine):
         assert res[0].status == er.status, (t, res[0].status, er.status)
         if er.status == 0:
             assert out.raw[:res[0].out_len] == eo
+
+
+@pytest.mark.parametrize("name", ["powerpc", "ia64", "arm", "armthumb", "sparc"])
+def test_other_bcj_filters(engine, name):
+    # xz-bcj-filters.lisp:45-167, chains as the reference builds them (xz.lisp:311-344)
+    lz_id = {"powerpc": lzma.FILTER_POWERPC, "ia64": lzma.FILTER_IA64, "arm": lzma.FILTER_ARM,
+             "armthumb": lzma.FILTER_ARMTHUMB, "sparc": lzma.FILTER_SPARC}[name]
+    d = corpus.random_bytes(250001, seed=4) + corpus.x86ish(40000, seed=8)
+    for filters in ([{"id": lz_id}, {"id": lzma.FILTER_LZMA2, "preset": 3}],
+                    [{"id": lz_id, "start_offset": 1 << 16}, {"id": lzma.FILTER_LZMA2, "preset": 1}],
+                    [{"id": lzma.FILTER_DELTA, "dist": 4}, {"id": lz_id}, {"id": lzma.FILTER_LZMA2, "preset": 1}]):
+        check_xz(engine, xzutil.xz_py(d, lzma.CHECK_CRC64, filters), d)
+    # unaligned block starts inside the output: multi-block stream through the CLI
+    data = xzutil.xz_cli(d, "--block-size=70001", f"--{name}", "--lzma2=preset=1", "--check=crc32")
+    check_xz(engine, data, d)
+
+
+def test_arm64_bcj_filter(engine):
+    rng = random.Random(5)
+    words = [0x94000000 | rng.getrandbits(26) if rng.random() < 0.2 else
+             0x90000000 | (rng.getrandbits(2) << 29) | (rng.getrandbits(19) << 5) | rng.getrandbits(5) if rng.random() < 0.25 else
+             rng.getrandbits(32) for _ in range(60000)]
+    d = b"".join(w.to_bytes(4, "little") for w in words) + b"\x07"
+    check_xz(engine, xzutil.xz_single_block(xzutil.arm64_encode(d), d, 0x0A, oracle.crc64), d)

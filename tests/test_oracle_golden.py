@@ -16,6 +16,7 @@ import zlib
 import pytest
 
 import corpus
+import xzutil
 from oracle import oracle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -263,3 +264,46 @@ def test_bcj_x86_and_delta_vs_liblzma():
                                                            {"id": lzma.FILTER_LZMA2, "preset": 0}])
         mid = lzma.decompress(enc, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 0}])
         assert oracle.delta(mid, dist) == d
+
+
+BCJ_IDS = {"powerpc": (lzma.FILTER_POWERPC, 5), "ia64": (lzma.FILTER_IA64, 6), "arm": (lzma.FILTER_ARM, 7),
+           "armthumb": (lzma.FILTER_ARMTHUMB, 8), "sparc": (lzma.FILTER_SPARC, 9)}
+
+
+@pytest.mark.parametrize("name", sorted(BCJ_IDS))
+def test_other_bcj_filters_vs_liblzma(name):
+    # xz-bcj-filters.lisp:45-167: liblzma's raw encoder applies the forward filter, the oracle's inverse undoes it,
+    # and the oracle's member decoder accepts the same chain inside a container
+    lz_id, xz_id = BCJ_IDS[name]
+    d = corpus.random_bytes(120000, seed=9) + corpus.x86ish(30003, seed=2)       # random words hit every pattern
+    for start in (0, 4096):
+        enc = lzma.compress(d, lzma.FORMAT_RAW, filters=[{"id": lz_id, "start_offset": start}, {"id": lzma.FILTER_LZMA2, "preset": 0}])
+        mid = lzma.decompress(enc, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 0}])
+        assert mid != d
+        assert oracle.bcj_simple(mid, xz_id, start) == d
+        blob = xzutil.xz_py(d, lzma.CHECK_CRC32, [{"id": lz_id, "start_offset": start}, {"id": lzma.FILTER_LZMA2, "preset": 1}])
+        r, o = oracle.decompress(8, blob, True, cap=len(d) + 16)
+        assert r.status == 0 and o == d
+
+
+def test_arm64_bcj_round_trip():
+    # no ARM64 encoder in liblzma 5.2.5: the forward filter is tests/xzutil.py (after XZ Utils 5.4 arm64.c); parity of
+    # the decoder direction is pinned by reading xz-bcj-filters.lisp:55-80
+    rng = random.Random(3)
+    words = []
+    for _ in range(30000):
+        k = rng.random()
+        if k < 0.2:
+            words.append(0x94000000 | rng.getrandbits(26))                       # BL
+        elif k < 0.4:
+            words.append(0x90000000 | (rng.getrandbits(2) << 29) | (rng.getrandbits(19) << 5) | rng.getrandbits(5))  # ADRP
+        else:
+            words.append(rng.getrandbits(32))
+    d = b"".join(w.to_bytes(4, "little") for w in words) + b"\x01\x02\x03"
+    for start in (0, 1 << 20):
+        enc = xzutil.arm64_encode(d, start)
+        assert enc != d
+        assert oracle.bcj_simple(enc, 0x0A, start) == d
+    blob = xzutil.xz_single_block(xzutil.arm64_encode(d), d, 0x0A, oracle.crc64)
+    r, o = oracle.decompress(8, blob, True, cap=len(d) + 16)
+    assert r.status == 0 and o == d

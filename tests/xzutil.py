@@ -26,3 +26,52 @@ def bgzf(data, block=60000, level=6):
         out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + (6).to_bytes(2, "little") + b"BC\x02\x00" + bsize.to_bytes(2, "little")
         out += body + zlib.crc32(chunk).to_bytes(4, "little") + (len(chunk) & 0xFFFFFFFF).to_bytes(4, "little")
     return bytes(out)
+
+
+def arm64_encode(data, start=0):
+    """Forward ARM64 BCJ filter (XZ Utils 5.4 src/liblzma/simple/arm64.c with is_encoder set): liblzma 5.2.5
+    and CPython's lzma have no ARM64 encoder, so the test corpus for the decoder is made here."""
+    b = bytearray(data)
+    for i in range(0, len(b) - 3, 4):
+        instr = int.from_bytes(b[i:i + 4], "little")
+        pc = (start + i) & 0xFFFFFFFF
+        if instr >> 26 == 0x25:
+            instr = 0x94000000 | ((instr + (pc >> 2)) & 0x03FFFFFF)
+        elif instr & 0x9F000000 == 0x90000000:
+            src = ((instr >> 29) & 3) | ((instr >> 3) & 0x001FFFFC)
+            if (src + 0x00020000) & 0x001C0000:
+                continue
+            dest = (src + (pc >> 12)) & 0xFFFFFFFF
+            instr = (instr & 0x9000001F) | ((dest & 3) << 29) | ((dest & 0x0003FFFC) << 3) | ((0 - (dest & 0x00020000)) & 0x00E00000)
+        else:
+            continue
+        b[i:i + 4] = instr.to_bytes(4, "little")
+    return bytes(b)
+
+
+def xz_single_block(filtered, plain, filter_id, crc64):
+    """A one-block .xz stream by hand: `filtered` is LZMA2-compressed behind the BCJ filter `filter_id`
+    (no properties), the CRC64 check is the one of `plain`.  crc64: a function bytes -> int."""
+    import zlib
+
+    def varint(v):
+        out = bytearray()
+        while True:
+            out.append(v & 0x7F)
+            v >>= 7
+            if not v:
+                return bytes(out)
+            out[-1] |= 0x80
+
+    def with_crc(body):
+        return body + zlib.crc32(body).to_bytes(4, "little")
+
+    raw = lzma.compress(filtered, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 6, "dict_size": 1 << 20}])
+    flags = b"\x00\x04"                                                  # CRC64
+    header = b"\xfd7zXZ\x00" + with_crc(flags)
+    bh = bytes([2, 0x01, filter_id, 0x00, 0x21, 0x01, 16, 0x00])         # 12-byte header, two filters, 1 MiB dictionary
+    block = with_crc(bh) + raw + b"\0" * (-len(raw) % 4) + crc64(plain).to_bytes(8, "little")
+    index = b"\x00" + varint(1) + varint(12 + len(raw) + 8) + varint(len(plain))
+    index = with_crc(index + b"\0" * (-len(index) % 4))
+    footer = ((len(index) // 4) - 1).to_bytes(4, "little") + flags
+    return header + block + index + zlib.crc32(footer).to_bytes(4, "little") + footer + b"YZ"
