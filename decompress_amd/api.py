@@ -17,8 +17,8 @@ the CFFI glue a maintainer of the Lisp library would add instead.
     adler_32(data, start=0, end=None)                adler32.lisp:76-87
 
 Formats are the reference's keywords as strings: "deflate", "zlib", "gzip",
-"bzip2", "xz" (":raw-lzma2" units are reachable through Engine.decode_batch;
-the .lzma "alone" format is a SURVEY.md 8f "next" row).  Everything decodes on
+"bzip2", "xz", "raw-lzma2" (needs window_size=, lzma2.lisp:206-218) and "lzma2"
+(the .lzma "alone" format is a SURVEY.md 8f "next" row).  Everything decodes on
 the GPU; there is no CPU fallback: without the built library or without a GPU
 the calls raise EngineError.
 """
@@ -28,7 +28,7 @@ import zlib as _zlib
 from . import _lib
 
 FORMATS = {"deflate": _lib.FMT_DEFLATE, "zlib": _lib.FMT_ZLIB, "gzip": _lib.FMT_GZIP, "bzip2": _lib.FMT_BZIP2,
-           "xz": _lib.FMT_XZ}
+           "xz": _lib.FMT_XZ, "raw-lzma2": _lib.FMT_RAW_LZMA2, "lzma2": _lib.FMT_LZMA2}
 
 
 class DecompressionError(Exception):
@@ -106,7 +106,17 @@ def _header(fmt, data, res, info):
         return {"block_size": 100000 * h[0]}
     if fmt == "xz":
         return {"checksum_type": h[0]}
+    if fmt == "lzma2":
+        return {"window_size": h[0]}                      # lzma2.lisp:226-227
     return None
+
+
+def _format_options(format, window_size):
+    """Format keywords that reach the decoder: :window-size of :raw-lzma2 (lzma2.lisp:206-213)."""
+    if format == "raw-lzma2":
+        if not isinstance(window_size, int) or window_size < 0:       # check-type window-size unsigned-byte
+            raise TypeError("raw-lzma2 needs window_size= (an unsigned integer)")
+        _get_engine().set_option("window-size", min(window_size, 0xFFFFFFFF))
 
 
 def _zlib_with_dictionary(data, dictionary, window_size):
@@ -150,6 +160,7 @@ def decompress(format, input, start=0, end=None, output_size=None, all_members_p
         if all_members_p and used != len(data):
             _raise(170, 0)
         return payload, {"window_size": 1 << ((data[0] >> 4) + 8), "level": data[1] >> 6, "dictionary": r.aux}
+    _format_options(format, window_size)
     payload, res, info = _get_engine().decode_stream(FORMATS[format], data, all_members_p)
     if res.status != 0:
         _raise(res.status, res.detail)
@@ -182,6 +193,9 @@ class DecompressionStream(io.BytesIO):
         else:
             data = _normalize_bounds(input, kw.pop("start", 0), kw.pop("end", None))
         self.format = format
+        if format not in FORMATS:
+            raise ValueError(f"unknown format {format!r}; supported: {list_supported_formats()}")
+        _format_options(format, kw.get("window_size"))
         payload, res, info = _get_engine().decode_stream(FORMATS[format], data, all_members_p)
         self._pending = None if res.status == 0 else (res.status, res.detail)
         self.header = _header(format, data, res, info)

@@ -98,6 +98,11 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
 {
     if (!c || !name) return -1;
     if (!strcmp(name, "profile")) { c->profile = value != 0; return 0; }
+    if (!strcmp(name, "window-size")) {
+        if (value < 0) return semz_fail(c, -1, "window-size must be an unsigned integer");   // check-type, lzma2.lisp:212
+        c->window_size = (uint64_t)value;
+        return 0;
+    }
     return semz_fail(c, -1, "unknown option %s", name);
 }
 

@@ -22,6 +22,8 @@ struct semz_ctx {
     std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
     // optional per-kernel timing (semz_set_option "profile"): event pairs on `stream`
     bool profile = false;
+    // :window-size of the :raw-lzma2 format (lzma2.lisp:206-218), semz_set_option "window-size"
+    uint64_t window_size = 0xFFFFFFFFull;
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};

@@ -441,6 +441,35 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
     }
 }
 
+// ---- :raw-lzma2 / :lzma2 (lzma2.lisp:205-227): one unit, no members ----
+int run_lzma2(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *info)
+{
+    uint64_t start = 0;
+    uint32_t dict = (uint32_t)(R.c->window_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : R.c->window_size);   // min(window-size, 2^32 - 1)
+    if (fmt == SEMZ_FMT_LZMA2) {
+        if (R.in_len < 1) { oc.status = SEMZ_EOF; return 0; }
+        const uint32_t o = R.in[0];                        // parse-lzma2-dict-size, lzma2.lisp:40-46
+        if (o > 40) { oc.status = SEMZ_E_LZMA2_DICT_BYTE; oc.detail = o; oc.consumed = 1; return 0; }
+        dict = o == 40 ? 0xFFFFFFFFu : (2u | (o & 1)) << (11 + o / 2);
+        start = 1;
+    }
+    if (info) info->first_header[0] = dict;                // header plist (:window-size n)
+    semz_unit u{};
+    u.in_off = start;
+    u.in_limit = R.in_len;
+    u.kind = SEMZ_UNIT_LZMA2;
+    u.param0 = dict;
+    semz_result r{};
+    int rc = R.decode_one(u, r, std::max<uint64_t>(1 << 20, 8 * R.in_len));
+    if (rc) return rc;
+    oc.consumed = (r.in_end_bit + 7) / 8;
+    if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
+    R.emit(r.out_off, r.out_len);
+    if (info) info->nmembers = 1;
+    if (all_members && oc.consumed != R.in_len) oc.status = SEMZ_E_TRAILING_DATA;       // interface.lisp:125-130
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t **out,
@@ -471,6 +500,8 @@ extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_
     }
     case SEMZ_FMT_BZIP2: rc = run_bzip2(R, all_members != 0, oc, &si); break;
     case SEMZ_FMT_XZ: rc = run_xz(R, all_members != 0, oc, &si); break;
+    case SEMZ_FMT_RAW_LZMA2:
+    case SEMZ_FMT_LZMA2: rc = run_lzma2(R, fmt, all_members != 0, oc, &si); break;
     default: return semz_fail(c, -1, "format %d has no stream decoder yet", fmt);
     }
     if (rc) return rc;

@@ -142,7 +142,9 @@ int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
 int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
                              const semz_unit *d_units, size_t nunits,
                              void *d_out, size_t out_cap, semz_result *d_results);
-/* Options: "profile" = 1 records a HIP event pair around every kernel of later calls. */
+/* Options: "profile" = 1 records a HIP event pair around every kernel of later calls.
+ * "window-size" = the :window-size keyword of the :raw-lzma2 format (lzma2.lisp:206-218; values
+ * above 2^32-1 are clipped as there), used by semz_decode_stream(SEMZ_FMT_RAW_LZMA2). */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */

@@ -31,6 +31,16 @@ void orc_decompress(int fmt, const uint8_t *in, size_t in_len, int all_members,
         case 2: { orc_gzip_header h; orc_gzip_member(p, n, out + outn, out_cap - outn, &h, &r); break; }
         case 3: orc_bzip2_member(p, n, out + outn, out_cap - outn, &r); break;
         case 6: orc_lzma2(p, n, 0, 0, opt, out + outn, out_cap - outn, &r); break;
+        case 7: {                                          /* :lzma2 = dictionary size byte + :raw-lzma2, lzma2.lisp:222-227 */
+            memset(&r, 0, sizeof r);
+            if (n < 1) { r.status = SEMZ_EOF; break; }
+            unsigned o = p[0];                             /* parse-lzma2-dict-size, lzma2.lisp:40-46 */
+            if (o > 40) { r.status = SEMZ_E_LZMA2_DICT_BYTE; r.detail = o; r.in_end_bit = 8; break; }
+            uint32_t ds = o == 40 ? 0xFFFFFFFFu : (2u | (o & 1)) << (11 + o / 2);
+            orc_lzma2(p + 1, n - 1, 0, 0, ds, out + outn, out_cap - outn, &r);
+            r.in_end_bit += 8;
+            break;
+        }
         case 8: orc_xz_member_ex(p, n, skip_magic, out + outn, out_cap - outn, &r); break;
         default: r.status = SEMZ_E_UNSUPPORTED; r.detail = 0; r.in_end_bit = 0; r.out_len = 0;
         }

@@ -141,5 +141,5 @@ def delta(buf, distance):
 
 
 def decompress(fmt, data, all_members=True, opt=0, cap=1 << 22):
-    """Mirror of decompress / decompress-all. fmt: 0 deflate 1 zlib 2 gzip 3 bzip2 6 raw-lzma2 8 xz."""
+    """Mirror of decompress / decompress-all. fmt: 0 deflate 1 zlib 2 gzip 3 bzip2 6 raw-lzma2 (opt = window size) 7 lzma2 8 xz."""
     return _run(lambda *a: lib().orc_decompress(fmt, bytes(data), len(data), int(all_members), opt, *a), cap)

@@ -66,3 +66,26 @@ def test_conditions():
     with pytest.raises(api.DecompressionError):
         s.read()
     assert api.adler_32(bytes([1, 33, 7])) == 5177386
+
+
+def test_lzma2_formats():
+    """:raw-lzma2 takes :window-size (lzma2.lisp:206-213); :lzma2 reports it in the header (lzma2.lisp:222-227)."""
+    import lzma
+    d = b"lzma2 through the public interface " * 300
+    raw = lzma.compress(d, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 2, "dict_size": 1 << 16}])
+    out, header = api.decompress("raw-lzma2", raw, window_size=1 << 16)
+    assert out == d and header is None
+    out, _ = api.decompress("raw-lzma2", raw, window_size=1 << 40)      # clipped to 2^32 - 1
+    assert out == d
+    with pytest.raises(TypeError):
+        api.decompress("raw-lzma2", raw)
+    out, header = api.decompress("lzma2", bytes([10]) + raw)
+    assert out == d and header == {"window_size": 1 << 17}
+    with pytest.raises(api.DecompressionError) as e:
+        api.decompress("lzma2", bytes([41]) + raw)
+    assert e.value.status == 101
+    with pytest.raises(api.DecompressionError) as e:
+        api.decompress_all("lzma2", bytes([10]) + raw + b"\0")
+    assert e.value.status == 170
+    s = api.make_decompression_stream("raw-lzma2", raw, window_size=1 << 16)
+    assert s.read() == d

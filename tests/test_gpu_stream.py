@@ -21,9 +21,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FMT = {"deflate": 0, "zlib": 1, "gzip": 2, "bzip2": 3, "xz": 8}
 
 
-def compare(engine, fmt, data, all_members=True, cap=1 << 23):
+def compare(engine, fmt, data, all_members=True, cap=1 << 23, opt=0):
+    if fmt == 6:
+        engine.set_option("window-size", opt)
     got, res, info = engine.decode_stream(fmt, data, all_members)
-    er, eo = oracle.decompress(fmt, data, all_members, cap=cap)
+    er, eo = oracle.decompress(fmt, data, all_members, opt=opt, cap=cap)
     assert res.status == er.status, (fmt, len(data), res.status, er.status, res.detail, er.detail)
     if er.status == 0:
         assert got == eo
@@ -126,3 +128,33 @@ def test_xz_streams(engine):
         bad[where] ^= 1 << rng.randrange(8)
         compare(engine, 8, bytes(bad))
     compare(engine, 8, xzutil.xz_py(b"", lzma.CHECK_CRC64))     # a member without blocks
+
+
+def test_lzma2_streams(engine):
+    """:raw-lzma2 (window size from the caller) and :lzma2 (dictionary size byte first), lzma2.lisp:205-227."""
+    d = corpus.mixed(300000, seed=13)
+    raw = lzma.compress(d, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 5, "dict_size": 1 << 18}])
+    got, res, _ = compare(engine, 6, raw, opt=1 << 18)
+    assert got == d and res.status == 0
+    compare(engine, 6, raw, opt=4096)                            # distances beyond the caller's window are rejected
+    compare(engine, 6, raw + b"tail", opt=1 << 18)                         # no multi-member support: trailing data
+    got, res, _ = compare(engine, 6, raw + b"tail", all_members=False, opt=1 << 18)
+    assert got == d and res.in_end_bit == 8 * len(raw)
+    compare(engine, 6, raw[:len(raw) // 2], opt=1 << 18)
+    compare(engine, 6, b"", opt=1 << 18)
+    for o in (0, 1, 14, 15, 18, 39, 40):                         # 2^18 needs byte 14; smaller windows fail on distance
+        got, res, info = compare(engine, 7, bytes([o]) + raw)
+        want = 0xFFFFFFFF if o == 40 else (2 | (o & 1)) << (11 + o // 2)
+        assert info.first_header[0] == want
+        assert (res.status == 0 and got == d) == (want >= 1 << 18)
+    for o in (41, 200, 255):
+        _, res, _ = compare(engine, 7, bytes([o]) + raw)
+        assert res.status == 101 and res.detail == o
+    compare(engine, 7, b"")
+    compare(engine, 7, bytes([20]))
+    compare(engine, 7, bytes([20]) + raw + b"x")
+    rng = random.Random(14)
+    for _ in range(12):
+        bad = bytearray(bytes([16]) + raw)
+        bad[rng.randrange(1, len(bad))] ^= 1 << rng.randrange(8)
+        compare(engine, 7, bytes(bad))

@@ -307,3 +307,24 @@ def test_arm64_bcj_round_trip():
     blob = xzutil.xz_single_block(xzutil.arm64_encode(d), d, 0x0A, oracle.crc64)
     r, o = oracle.decompress(8, blob, True, cap=len(d) + 16)
     assert r.status == 0 and o == d
+
+
+def test_lzma2_formats():
+    """:raw-lzma2 / :lzma2 through the decompress mirror (lzma2.lisp:205-227) against liblzma's raw encoder."""
+    d = corpus.mixed(50000, seed=21)
+    raw = lzma.compress(d, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 4, "dict_size": 1 << 16}])
+    r, out = oracle.decompress(6, raw, True, opt=1 << 16, cap=len(d) + 8)
+    assert r.status == 0 and out == d and r.in_end_bit == 8 * len(raw)
+    r, _ = oracle.decompress(6, raw + b"x", True, opt=1 << 16, cap=len(d) + 8)
+    assert r.status == 170                                        # trailing data: no multi-member support
+    r, out = oracle.decompress(6, raw + b"x", False, opt=1 << 16, cap=len(d) + 8)
+    assert r.status == 0 and out == d
+    for o, want in ((0, 4096), (1, 6144), (10, 1 << 17), (11, 3 << 16), (39, 3 << 30), (40, 0xFFFFFFFF)):
+        r, out = oracle.decompress(7, bytes([o]) + raw, True, cap=len(d) + 8)
+        assert (r.status == 0 and out == d) == (want >= 1 << 16), (o, r.status)
+        if r.status == 0:
+            assert r.in_end_bit == 8 * (len(raw) + 1)
+    r, _ = oracle.decompress(7, bytes([41]) + raw, True, cap=len(d) + 8)
+    assert r.status == 101 and r.detail == 41                     # "Unrecognized LZMA2 dictionary size byte."
+    r, _ = oracle.decompress(7, b"", True)
+    assert r.status == 1
