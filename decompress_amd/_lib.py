@@ -41,7 +41,7 @@ class StreamInfo(C.Structure):
 
 
 # unit kinds / formats / flags (semz_gpu.h)
-UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2 = range(6)
+UNIT_DEFLATE, UNIT_ZLIB, UNIT_GZIP, UNIT_BZIP2_BLOCK, UNIT_XZ_BLOCK, UNIT_LZMA2, UNIT_LZMA, UNIT_LZMA_WIDE = range(8)
 FMT_DEFLATE, FMT_ZLIB, FMT_GZIP, FMT_BZIP2, FMT_RAW_LZMA, FMT_LZMA, FMT_RAW_LZMA2, FMT_LZMA2, FMT_XZ = range(9)
 UF_HAVE_DICT_FN, UF_HAVE_IN_SIZE, UF_HAVE_OUT_SIZE = 1, 4, 8
 FILTER_DELTA, FILTER_X86 = 1, 2

@@ -17,8 +17,9 @@ the CFFI glue a maintainer of the Lisp library would add instead.
     adler_32(data, start=0, end=None)                adler32.lisp:76-87
 
 Formats are the reference's keywords as strings: "deflate", "zlib", "gzip",
-"bzip2", "xz", "raw-lzma2" (needs window_size=, lzma2.lisp:206-218) and "lzma2"
-(the .lzma "alone" format is a SURVEY.md 8f "next" row).  Everything decodes on
+"bzip2", "xz", "raw-lzma2" (needs window_size=, lzma2.lisp:206-218), "lzma2",
+"lzma" (.lzma files) and "raw-lzma" (needs lc=, lp=, pb=, window_size=; takes
+decompressed_size= and eof_mode= "maybe" | "always" | "never", lzma.lisp:809-825).  Everything decodes on
 the GPU; there is no CPU fallback: without the built library or without a GPU
 the calls raise EngineError.
 """
@@ -28,7 +29,8 @@ import zlib as _zlib
 from . import _lib
 
 FORMATS = {"deflate": _lib.FMT_DEFLATE, "zlib": _lib.FMT_ZLIB, "gzip": _lib.FMT_GZIP, "bzip2": _lib.FMT_BZIP2,
-           "xz": _lib.FMT_XZ, "raw-lzma2": _lib.FMT_RAW_LZMA2, "lzma2": _lib.FMT_LZMA2}
+           "xz": _lib.FMT_XZ, "raw-lzma2": _lib.FMT_RAW_LZMA2, "lzma2": _lib.FMT_LZMA2,
+           "raw-lzma": _lib.FMT_RAW_LZMA, "lzma": _lib.FMT_LZMA}
 
 
 class DecompressionError(Exception):
@@ -108,15 +110,37 @@ def _header(fmt, data, res, info):
         return {"checksum_type": h[0]}
     if fmt == "lzma2":
         return {"window_size": h[0]}                      # lzma2.lisp:226-227
+    if fmt == "lzma":                                     # lzma.lisp:860-865
+        return {"lc": h[0], "lp": h[1], "pb": h[2], "window_size": h[3],
+                "decompressed_size": (h[6] << 32 | h[5]) if h[4] else None}
     return None
 
 
-def _format_options(format, window_size):
-    """Format keywords that reach the decoder: :window-size of :raw-lzma2 (lzma2.lisp:206-213)."""
-    if format == "raw-lzma2":
+_EOF_MODES = {None: 0, "maybe": 0, "always": 1, "never": 2}
+
+
+def _format_options(format, window_size, kw=None):
+    """Format keywords that reach the decoder: :window-size of :raw-lzma2 (lzma2.lisp:206-213) and the
+    keywords of :raw-lzma with their check-type ranges (lzma.lisp:811-825)."""
+    kw = kw or {}
+    if format in ("raw-lzma2", "raw-lzma"):
         if not isinstance(window_size, int) or window_size < 0:       # check-type window-size unsigned-byte
-            raise TypeError("raw-lzma2 needs window_size= (an unsigned integer)")
+            raise TypeError(f"{format} needs window_size= (an unsigned integer)")
         _get_engine().set_option("window-size", min(window_size, 0xFFFFFFFF))
+    if format == "raw-lzma":
+        eng = _get_engine()
+        for name, hi in (("lc", 8), ("lp", 4), ("pb", 4)):
+            v = kw.get(name)
+            if not isinstance(v, int) or not 0 <= v <= hi:
+                raise TypeError(f"raw-lzma needs {name}= in 0..{hi}")
+            eng.set_option(name, v)
+        size = kw.get("decompressed_size")
+        if size is not None and (not isinstance(size, int) or size < 0):
+            raise TypeError("decompressed_size must be None or an unsigned integer")
+        eng.set_option("decompressed-size", -1 if size is None else size)
+        if kw.get("eof_mode") not in _EOF_MODES:
+            raise TypeError("eof_mode must be 'always', 'never' or 'maybe'")
+        eng.set_option("eof-mode", _EOF_MODES[kw.get("eof_mode")])
 
 
 def _zlib_with_dictionary(data, dictionary, window_size):
@@ -140,7 +164,7 @@ def _zlib_with_dictionary(data, dictionary, window_size):
 
 
 def decompress(format, input, start=0, end=None, output_size=None, all_members_p=False, allow_overreads_p=False,
-               dictionary=None, window_size=None, **_ignored):
+               dictionary=None, window_size=None, **format_options):
     """Decompresses one member (or all, with all_members_p) of `input` (bytes-like or a binary file object).
 
     Returns (bytes, header) like the reference's two values; raises DecompressionError / EOF.
@@ -160,7 +184,7 @@ def decompress(format, input, start=0, end=None, output_size=None, all_members_p
         if all_members_p and used != len(data):
             _raise(170, 0)
         return payload, {"window_size": 1 << ((data[0] >> 4) + 8), "level": data[1] >> 6, "dictionary": r.aux}
-    _format_options(format, window_size)
+    _format_options(format, window_size, format_options)
     payload, res, info = _get_engine().decode_stream(FORMATS[format], data, all_members_p)
     if res.status != 0:
         _raise(res.status, res.detail)
@@ -195,7 +219,7 @@ class DecompressionStream(io.BytesIO):
         self.format = format
         if format not in FORMATS:
             raise ValueError(f"unknown format {format!r}; supported: {list_supported_formats()}")
-        _format_options(format, kw.get("window_size"))
+        _format_options(format, kw.get("window_size"), kw)
         payload, res, info = _get_engine().decode_stream(FORMATS[format], data, all_members_p)
         self._pending = None if res.status == 0 else (res.status, res.detail)
         self.header = _header(format, data, res, info)

@@ -3,7 +3,8 @@
 // Replaces, per unit, the reference loops
 //   lzma-range-decoder, lrd-*            lzma.lisp:49-198
 //   decode-lzma-length / -distance       lzma.lisp:247-341
-//   decode-lzma (eof-mode :never)        lzma.lisp:566-775
+//   decode-lzma (all eof modes)          lzma.lisp:566-775
+//   :raw-lzma chunk method               lzma.lisp:867-895
 //   LZMA2 control-byte state machine     lzma2.lisp:77-204
 //   xz block end (sizes, padding, check) xz.lisp:426-457
 //   x86 BCJ filter                       xz-bcj-filters.lisp:169-219
@@ -127,6 +128,19 @@ struct Lz {
         normalize();
         return b;
     }
+    // same over probabilities kept in HBM (the literal coder of SEMZ_UNIT_LZMA_WIDE); L2-coherent accesses, so
+    // that the wave reads back its own updates
+    __device__ __forceinline__ uint32_t bit_g(uint16_t *probs, uint32_t idx)
+    {
+        const uint32_t p = uni((uint32_t)__hip_atomic_load(probs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const uint32_t bound = p * (range >> 11);
+        uint32_t b, np;
+        if (code >= bound) { range -= bound; code -= bound; np = p - (p >> 5); b = 1; }
+        else { range = bound; np = p + ((2048 - p) >> 5); b = 0; }
+        if ((threadIdx.x & 63) == 0) __hip_atomic_store(probs + idx, (uint16_t)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        normalize();
+        return b;
+    }
     __device__ __forceinline__ uint32_t be_bits(uint16_t *probs, uint32_t base, uint32_t count)   // lzma.lisp:122-135
     {
         const uint32_t bound = 1u << count;
@@ -178,8 +192,13 @@ __device__ __forceinline__ uint32_t ld_bytes_le(const uint8_t *p, int n)
     return v;
 }
 
+enum { EOF_MAYBE = 0, EOF_ALWAYS = 1, EOF_NEVER = 2 };          // eof-mode, lzma.lisp:575-577
+constexpr uint32_t WIDE_LIT_PROBS = 0x300u << 12;               // lc <= 8, lp <= 4 (lzma.lisp:818-819)
+
+// WIDE: the literal coder's probabilities live in `wide` (WIDE_LIT_PROBS entries per unit) instead of LDS
+template <bool WIDE>
 __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                      uint8_t *out, semz_result *results, semz_tail *tails)
+                                                      uint8_t *out, semz_result *results, semz_tail *tails, uint16_t *wide)
 {
     __shared__ LzLds L;
     const uint32_t lane = threadIdx.x & 63;
@@ -198,6 +217,8 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
     const uint64_t out_cap = un.out_cap;
     const uint32_t dict_size = un.param0;
     const bool is_xz = un.kind == SEMZ_UNIT_XZ_BLOCK;
+    const bool is_lzma1 = un.kind == SEMZ_UNIT_LZMA || un.kind == SEMZ_UNIT_LZMA_WIDE;
+    uint16_t *const wlit = WIDE ? wide + (size_t)u * WIDE_LIT_PROBS : nullptr;
     uint8_t *safe_byte = out;                          // always-readable address for masked-off gather lanes
 
     const uint64_t amis = (uint64_t)((uintptr_t)in & 3);
@@ -265,12 +286,71 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
         return uni((uint32_t)__hip_atomic_load(ob + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     };
 
-    // ---- LZMA2 control loop (lzma2.lisp:77-204) ----
+    // literal coder bit: probabilities in LDS, or in HBM for the wide contexts of :raw-lzma
+    auto lit_bit = [&](uint32_t idx) -> uint32_t {
+        if constexpr (WIDE) return z.bit_g(wlit, idx);
+        else return z.bit(L.probs, P_LIT + idx);
+    };
+
+    // ---- LZMA2 control loop (lzma2.lisp:77-204); a :raw-lzma unit passes through it once as one "chunk" ----
+    bool lzma1_started = false;
     for (;;) {
         if (z.status != SEMZ_OK) break;
-        const uint32_t control = z.next_byte();
-        if (z.status != SEMZ_OK) break;
-        if (control >= 0x80) {
+        uint64_t end;                  // the variable P of lzma.lisp:532-551; ~0 = no declared size
+        uint64_t cap_end = ~0ull;      // where the output span ends, for data without a declared size
+        uint32_t eof_mode = EOF_NEVER; // lzma2.lisp:133
+        bool fresh;
+        if (is_lzma1) {
+            // :raw-lzma (lzma.lisp:809-835): properties and sizes come from the caller or the .lzma header
+            if (lzma1_started) break;
+            lzma1_started = true;
+            const uint32_t nlc = un.param1 & 0xFF, nlp = (un.param1 >> 8) & 0xFF, npb = (un.param1 >> 16) & 0xFF;
+            if (nlc > 8 || nlp > 4 || npb > 4 || (!WIDE && nlc + nlp > 4) || un.param2 > EOF_NEVER) {
+                z.fail(SEMZ_E_UNSUPPORTED, 2);        // check-type in the reference; wide contexts need SEMZ_UNIT_LZMA_WIDE
+                break;
+            }
+            lc = nlc; lp_mask = (1u << nlp) - 1; pb_mask = (1u << npb) - 1;
+            end = (un.flags & SEMZ_UF_HAVE_OUT_SIZE) ? un.size_out : ~0ull;
+            cap_end = out_cap;
+            eof_mode = un.param2;
+            fresh = true;
+        } else {
+            const uint32_t control = z.next_byte();
+            if (z.status != SEMZ_OK) break;
+            if (control == 0) break;                                 // end of the LZMA2 stream
+            if (control < 0x80) {
+                if (control > 2) { z.fail(SEMZ_E_LZMA2_CONTROL, control); break; }
+                // stored chunk (lzma2.lisp:152-189)
+                const uint32_t b0 = z.next_byte(), b1 = z.next_byte();
+                if (z.status != SEMZ_OK) break;
+                const uint64_t usize = ((b0 << 8) | b1) + 1;
+                if (control == 2) {
+                    if (need == NEED_DICT) { z.fail(SEMZ_E_LZMA2_NEED_DICT_RESET, 0); break; }
+                    need = NEED_NONE;
+                } else {
+                    need = NEED_PROPS;
+                    dict_base = p;
+                }
+                if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
+                if (z.pos + usize > z.rd_end) {                          // bs-read-sequence with eof-error-p
+                    z.pos = z.rd_end;
+                    (void)z.next_byte();
+                    break;
+                }
+                const uint8_t *src = in + (z.pos - amis);
+                lds_sync();
+                for (uint64_t off = 0; off < usize; off += LZ_FLUSH) {
+                    const uint32_t n = usize - off < (uint64_t)LZ_FLUSH ? (uint32_t)(usize - off) : (uint32_t)LZ_FLUSH;
+                    for (uint32_t k = lane; k < n; k += 64) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = src[off + k];
+                    p += n;
+                    lds_sync();
+                    flush(false);
+                }
+                z.pos += usize;
+                z.load_cur();
+                if (have_state) total_i = (total_i + (uint32_t)usize) & 15;   // lzma2.lisp:184-188
+                continue;
+            }
             uint32_t b0 = z.next_byte(), b1 = z.next_byte(), b2 = z.next_byte(), b3 = z.next_byte();
             if (z.status != SEMZ_OK) break;
             const uint64_t usize = (((uint64_t)(control & 31) << 16) | (b0 << 8) | b1) + 1;
@@ -288,158 +368,146 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
             } else if (!have_state) { z.fail(SEMZ_E_LZMA2_NO_STATE, 0); break; }
             if (control >= 0xE0) dict_base = p;
             if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
-            // counted source for the chunk (lzma2.lisp:111-116), then the range decoder (lzma.lisp:55-62)
+            // counted source for the chunk (lzma2.lisp:111-116)
             z.chunk_end = z.pos + csize;
             z.set_limits();
-            if (z.next_byte() != 0) z.fail(SEMZ_E_LZMA_FIRST_BYTE, 0);
-            z.range = 0xFFFFFFFFu;
-            z.code = 0;
-            for (int i = 0; i < 4; i++) z.code = (z.code << 8) | z.next_byte();
-            if (z.status == SEMZ_OK && !(z.code < z.range)) z.fail(SEMZ_E_LZMA_CODE_START, 0);
-            if (z.status != SEMZ_OK) break;
-            if (control >= 0xA0 || !have_state) {                   // fresh lzma-state-vars (lzma2.lisp:144-145)
-                for (uint32_t i = lane; i < (uint32_t)P_TOTAL; i += 64) L.probs[i] = 1024;
-                rep0 = rep1 = rep2 = rep3 = 0; history = 0; total_i = 0;
-                lds_sync();
+            end = p + usize;
+            fresh = control >= 0xA0 || !have_state;                  // fresh lzma-state-vars (lzma2.lisp:144-145)
+        }
+        // the range decoder (lzma.lisp:55-62)
+        if (z.next_byte() != 0) z.fail(SEMZ_E_LZMA_FIRST_BYTE, 0);
+        z.range = 0xFFFFFFFFu;
+        z.code = 0;
+        for (int i = 0; i < 4; i++) z.code = (z.code << 8) | z.next_byte();
+        if (z.status == SEMZ_OK && !(z.code < z.range)) z.fail(SEMZ_E_LZMA_CODE_START, 0);
+        if (z.status != SEMZ_OK) break;
+        if (fresh) {
+            for (uint32_t i = lane; i < (uint32_t)P_TOTAL; i += 64) L.probs[i] = 1024;
+            if constexpr (WIDE) {
+                const uint32_t n8 = (0x300u << (lc + __builtin_popcount(lp_mask))) / 8;      // 16-byte pieces
+                const uint4 fill = make_uint4(0x04000400u, 0x04000400u, 0x04000400u, 0x04000400u);
+                for (uint32_t i = lane; i < n8; i += 64) reinterpret_cast<uint4 *>(wlit)[i] = fill;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             }
-            have_state = true;
+            rep0 = rep1 = rep2 = rep3 = 0; history = 0; total_i = 0;
+            lds_sync();
+        }
+        have_state = true;
 
-            // ---- decode-lzma, eof-mode :never (lzma.lisp:566-775) ----
-            const uint64_t end = p + usize;
-            for (;;) {
-                if (z.status != SEMZ_OK) break;
-                const uint32_t pos_state = total_i & pb_mask;
-                if (p == end) {
-                    if (z.code != 0) {                               // handle-eof-insanity, lzma.lisp:644-647
-                        bool marker = false;                         // probe-eof, lzma.lisp:623-638
-                        if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 1 &&
-                            z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
-                            const uint32_t len = z.length(L.probs, P_LEN_SIMPLE, pos_state);
-                            marker = z.distance(L.probs, len) == 0xFFFFFFFFu;
-                        }
-                        z.fail(marker ? SEMZ_E_LZMA_ILLEGAL_EOF : SEMZ_E_LZMA_CONTINUES, 0);
+        // ---- decode-lzma (lzma.lisp:566-775) ----
+        bool eofp = false;
+        for (;;) {
+            if (z.status != SEMZ_OK) break;
+            const uint32_t pos_state = total_i & pb_mask;
+            if (p == end) {
+                // handle-eof-insanity (lzma.lisp:640-659): :always probes at once, the others ask the range decoder first
+                if (eof_mode == EOF_ALWAYS || z.code != 0) {
+                    bool marker = false;                             // probe-eof, lzma.lisp:623-638
+                    if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 1 &&
+                        z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
+                        const uint32_t len = z.length(L.probs, P_LEN_SIMPLE, pos_state);
+                        marker = z.distance(L.probs, len) == 0xFFFFFFFFu;
                     }
+                    if (eof_mode == EOF_NEVER) z.fail(marker ? SEMZ_E_LZMA_ILLEGAL_EOF : SEMZ_E_LZMA_CONTINUES, 0);
+                    else if (!marker) z.fail(eof_mode == EOF_ALWAYS ? SEMZ_E_LZMA_NO_EOF_MARKER : SEMZ_E_LZMA_NO_END, 0);
+                }
+                eofp = true;
+                break;
+            }
+            uint32_t len;
+            if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 0) {
+                // decode-literal, lzma.lisp:661-688
+                const uint32_t prev = p == dict_base ? 0u : uni((uint32_t)L.ring[(uint32_t)(p - 1 + shift) & LZ_MASK]);
+                const uint32_t base = 0x300u * (((total_i & lp_mask) << lc) | (prev >> (8 - lc)));
+                uint32_t symbol = 1;
+                if (history >= 7) {
+                    // decode-lzma-literal/match-case, lzma.lisp:497-518
+                    if (p - dict_base < (uint64_t)rep0 + 1) { z.fail(SEMZ_E_UNSUPPORTED, 1); break; }
+                    const uint32_t match_byte = history_byte(p - 1 - rep0);
+                    for (int bit_i = 7; bit_i >= 0; bit_i--) {
+                        const uint32_t mb = (match_byte >> bit_i) & 1;
+                        const uint32_t b = lit_bit(base + 0x100 + (mb << 8) + symbol);
+                        symbol = (symbol << 1) | b;
+                        if (mb != b) break;
+                    }
+                }
+                while (symbol < 0x100) symbol = (symbol << 1) | lit_bit(base + symbol);
+                if (p == cap_end) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
+                if (lane == 0) L.ring[(uint32_t)(p + shift) & LZ_MASK] = (uint8_t)symbol;
+                p++;
+                total_i++;
+                history = history < 4 ? 0 : history < 10 ? history - 3 : history - 6;   // lzma.lisp:615
+                if (p - flushed >= (uint64_t)LZ_FLUSH + 16) { lds_sync(); flush(false); }
+                continue;
+            }
+            if (z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
+                const uint32_t rl = z.length(L.probs, P_LEN_SIMPLE, pos_state);
+                history = history < 7 ? 7 : 10;
+                rep3 = rep2; rep2 = rep1; rep1 = rep0;
+                rep0 = z.distance(L.probs, rl);
+                if (rep0 == 0xFFFFFFFFu) {                                                  // lzma.lisp:727-732
+                    if (eof_mode == EOF_NEVER) z.fail(SEMZ_E_LZMA_ILLEGAL_EOF, 0);
+                    else eofp = true;
                     break;
                 }
-                uint32_t len;
-                if (z.bit(L.probs, P_IS_LIT + (history << 4) + pos_state) == 0) {
-                    // decode-literal, lzma.lisp:661-688
-                    const uint32_t prev = p == dict_base ? 0u : uni((uint32_t)L.ring[(uint32_t)(p - 1 + shift) & LZ_MASK]);
-                    const uint32_t base = P_LIT + 0x300u * (((total_i & lp_mask) << lc) | (prev >> (8 - lc)));
-                    uint32_t symbol = 1;
-                    if (history >= 7) {
-                        // decode-lzma-literal/match-case, lzma.lisp:497-518
-                        if (p - dict_base < (uint64_t)rep0 + 1) { z.fail(SEMZ_E_UNSUPPORTED, 1); break; }
-                        const uint32_t match_byte = history_byte(p - 1 - rep0);
-                        for (int bit_i = 7; bit_i >= 0; bit_i--) {
-                            const uint32_t mb = (match_byte >> bit_i) & 1;
-                            const uint32_t b = z.bit(L.probs, base + 0x100 + (mb << 8) + symbol);
-                            symbol = (symbol << 1) | b;
-                            if (mb != b) break;
-                        }
-                    }
-                    while (symbol < 0x100) symbol = (symbol << 1) | z.bit(L.probs, base + symbol);
-                    if (lane == 0) L.ring[(uint32_t)(p + shift) & LZ_MASK] = (uint8_t)symbol;
-                    p++;
-                    total_i++;
-                    history = history < 4 ? 0 : history < 10 ? history - 3 : history - 6;   // lzma.lisp:615
-                    if (p - flushed >= (uint64_t)LZ_FLUSH + 16) { lds_sync(); flush(false); }
-                    continue;
-                }
-                if (z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
-                    const uint32_t rl = z.length(L.probs, P_LEN_SIMPLE, pos_state);
-                    history = history < 7 ? 7 : 10;
-                    rep3 = rep2; rep2 = rep1; rep1 = rep0;
-                    rep0 = z.distance(L.probs, rl);
-                    if (rep0 == 0xFFFFFFFFu) { z.fail(SEMZ_E_LZMA_ILLEGAL_EOF, 0); break; }   // lzma.lisp:727-730
-                    len = rl + 2;
-                } else if (z.bit(L.probs, P_USES_REP0 + history) == 0) {
-                    if (z.bit(L.probs, P_IS_SHORT + (history << 4) + pos_state) == 0) {
-                        history = history < 7 ? 9 : 11;
-                        len = 1;
-                    } else {
-                        history = history < 7 ? 8 : 11;
-                        len = 2 + z.length(L.probs, P_LEN_REP, pos_state);
-                    }
+                len = rl + 2;
+            } else if (z.bit(L.probs, P_USES_REP0 + history) == 0) {
+                if (z.bit(L.probs, P_IS_SHORT + (history << 4) + pos_state) == 0) {
+                    history = history < 7 ? 9 : 11;
+                    len = 1;
                 } else {
-                    uint32_t t;
-                    if (z.bit(L.probs, P_IS_REP1 + history) == 0) { t = rep1; rep1 = rep0; rep0 = t; }
-                    else if (z.bit(L.probs, P_IS_REP2 + history) == 0) { t = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
-                    else { t = rep3; rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
                     history = history < 7 ? 8 : 11;
                     len = 2 + z.length(L.probs, P_LEN_REP, pos_state);
                 }
-                if (z.status != SEMZ_OK) break;
-                // handle-match, lzma.lisp:600-612
-                const uint64_t dist = (uint64_t)rep0 + 1;
-                if (!(dist <= dict_size)) { z.fail(SEMZ_E_LZMA_DICT_SIZE, 0); break; }
-                if (!(dist <= p - dict_base)) { z.fail(SEMZ_E_LZMA_NO_DATA, 0); break; }
-                if (!(p + len <= end)) { z.fail(SEMZ_E_LZMA_MATCH_SIZE, 0); break; }
-                {
-                    // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
-                    lds_sync();
-                    const uint64_t src = p - dist;
-                    const bool all_near = src + (LZ_RING - MAX_MATCH) > p + len;
-                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
-                        const uint32_t k = k0 + lane;
-                        const uint64_t s = src + (dist >= len ? k : k % (uint32_t)dist);
-                        uint32_t b;
-                        if (all_near) b = L.ring[(uint32_t)(s + shift) & LZ_MASK];
-                        else {
-                            const bool useg = k < len && s + (LZ_RING - MAX_MATCH) <= p;
-                            const uint32_t gv = __hip_atomic_load(useg ? ob + s : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const uint32_t lv = L.ring[(uint32_t)(s + shift) & LZ_MASK];
-                            b = useg ? gv : lv;
-                        }
-                        if (k < len) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = (uint8_t)b;
-                    }
-                    lds_sync();
-                }
-                p += len;
-                total_i += len;
-                if (p - flushed >= (uint64_t)LZ_FLUSH + 16) flush(false);
-            }
-            total_i &= 15;
-            if (z.status != SEMZ_OK) break;
-            if (z.pos != z.chunk_end) { z.fail(SEMZ_E_LZMA2_CHUNK_SHORT, 0); break; }   // lzma2.lisp:200-201
-            z.chunk_end = ~0ull;
-            z.set_limits();
-        } else if (control > 2) {
-            z.fail(SEMZ_E_LZMA2_CONTROL, control);
-            break;
-        } else if (control >= 1) {
-            // stored chunk (lzma2.lisp:152-189)
-            const uint32_t b0 = z.next_byte(), b1 = z.next_byte();
-            if (z.status != SEMZ_OK) break;
-            const uint64_t usize = ((b0 << 8) | b1) + 1;
-            if (control == 2) {
-                if (need == NEED_DICT) { z.fail(SEMZ_E_LZMA2_NEED_DICT_RESET, 0); break; }
-                need = NEED_NONE;
             } else {
-                need = NEED_PROPS;
-                dict_base = p;
+                uint32_t t;
+                if (z.bit(L.probs, P_IS_REP1 + history) == 0) { t = rep1; rep1 = rep0; rep0 = t; }
+                else if (z.bit(L.probs, P_IS_REP2 + history) == 0) { t = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                else { t = rep3; rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                history = history < 7 ? 8 : 11;
+                len = 2 + z.length(L.probs, P_LEN_REP, pos_state);
             }
-            if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
-            if (z.pos + usize > z.rd_end) {                          // bs-read-sequence with eof-error-p
-                z.pos = z.rd_end;
-                (void)z.next_byte();
-                break;
-            }
-            const uint8_t *src = in + (z.pos - amis);
-            lds_sync();
-            for (uint64_t off = 0; off < usize; off += LZ_FLUSH) {
-                const uint32_t n = usize - off < (uint64_t)LZ_FLUSH ? (uint32_t)(usize - off) : (uint32_t)LZ_FLUSH;
-                for (uint32_t k = lane; k < n; k += 64) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = src[off + k];
-                p += n;
+            if (z.status != SEMZ_OK) break;
+            // handle-match, lzma.lisp:600-612
+            const uint64_t dist = (uint64_t)rep0 + 1;
+            if (!(dist <= dict_size)) { z.fail(SEMZ_E_LZMA_DICT_SIZE, 0); break; }
+            if (!(dist <= p - dict_base)) { z.fail(SEMZ_E_LZMA_NO_DATA, 0); break; }
+            if (!(len <= end - p)) { z.fail(SEMZ_E_LZMA_MATCH_SIZE, 0); break; }
+            if (!(len <= cap_end - p)) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
+            {
+                // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
                 lds_sync();
-                flush(false);
+                const uint64_t src = p - dist;
+                const bool all_near = src + (LZ_RING - MAX_MATCH) > p + len;
+                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    const uint64_t s = src + (dist >= len ? k : k % (uint32_t)dist);
+                    uint32_t b;
+                    if (all_near) b = L.ring[(uint32_t)(s + shift) & LZ_MASK];
+                    else {
+                        const bool useg = k < len && s + (LZ_RING - MAX_MATCH) <= p;
+                        const uint32_t gv = __hip_atomic_load(useg ? ob + s : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t lv = L.ring[(uint32_t)(s + shift) & LZ_MASK];
+                        b = useg ? gv : lv;
+                    }
+                    if (k < len) L.ring[(uint32_t)(p + k + shift) & LZ_MASK] = (uint8_t)b;
+                }
+                lds_sync();
             }
-            z.pos += usize;
-            z.load_cur();
-            if (have_state) total_i = (total_i + (uint32_t)usize) & 15;   // lzma2.lisp:184-188
-        } else {
-            break;                                                   // end of the LZMA2 stream
+            p += len;
+            total_i += len;
+            if (p - flushed >= (uint64_t)LZ_FLUSH + 16) flush(false);
         }
+        total_i &= 15;
+        if (z.status != SEMZ_OK) break;
+        if (eofp && z.code != 0) { z.fail(SEMZ_E_LZMA_FINISH_STATE, 0); break; }          // lzma.lisp:772-774
+        if (is_lzma1) {
+            if (end != ~0ull && p != end) z.fail(SEMZ_E_LZMA_EARLY_END, 0);                 // lzma.lisp:891-894
+            break;
+        }
+        if (z.pos != z.chunk_end) { z.fail(SEMZ_E_LZMA2_CHUNK_SHORT, 0); break; }   // lzma2.lisp:200-201
+        z.chunk_end = ~0ull;
+        z.set_limits();
     }
     lds_sync();
     flush(true);
@@ -706,11 +774,18 @@ __global__ __launch_bounds__(256) void bcj_simple_kernel(const semz_unit *units,
 } // namespace
 
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
-                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide)
 {
     (void)in_len; (void)out_cap;
     semz_span_begin(c, "lzma2_kernel");
-    lzma2_kernel<<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails);
+    if (wide) {
+        void *w = nullptr;
+        int rc = semz_scratch(c, SEMZ_SLOT_LZ_WIDE, (size_t)nunits * WIDE_LIT_PROBS * sizeof(uint16_t), &w);
+        if (rc) return rc;
+        lzma2_kernel<true><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, (uint16_t *)w);
+    } else {
+        lzma2_kernel<false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr);
+    }
     semz_span_end(c);
     // filter chain stages (at most three non-last filters, xz.lisp:262); a kernel returns at once for
     // units whose chain has another filter, or none, at that stage

@@ -103,6 +103,17 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
         c->window_size = (uint64_t)value;
         return 0;
     }
+    // :raw-lzma keywords with the reference's check-type ranges (lzma.lisp:818-825)
+    if (!strcmp(name, "lc")) { if (value < 0 || value > 8) return semz_fail(c, -1, "lc must be in 0..8"); c->lz_lc = (int)value; return 0; }
+    if (!strcmp(name, "lp")) { if (value < 0 || value > 4) return semz_fail(c, -1, "lp must be in 0..4"); c->lz_lp = (int)value; return 0; }
+    if (!strcmp(name, "pb")) { if (value < 0 || value > 4) return semz_fail(c, -1, "pb must be in 0..4"); c->lz_pb = (int)value; return 0; }
+    if (!strcmp(name, "decompressed-size")) { c->lz_size = value < 0 ? -1 : value; return 0; }
+    if (!strcmp(name, "eof-mode")) {
+        if (value < 0 || value > 2) return semz_fail(c, -1, "eof-mode must be 0 (:maybe), 1 (:always) or 2 (:never)");
+        c->lz_eof_mode = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
 }
 
@@ -155,8 +166,10 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
         break;
     case SEMZ_UNIT_XZ_BLOCK:
     case SEMZ_UNIT_LZMA2:
+    case SEMZ_UNIT_LZMA:
+    case SEMZ_UNIT_LZMA_WIDE:
         rc = semz_run_lzma2(c, (const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,
-                            d_results, (semz_tail *)tails);
+                            d_results, (semz_tail *)tails, kind == SEMZ_UNIT_LZMA_WIDE);
         if (rc) return rc;
         break;
     default:
@@ -183,11 +196,13 @@ extern "C" int semz_decode_batch(semz_ctx *c, const uint8_t *in, size_t in_len, 
     if (!in || !units || !results || (!out && out_cap)) return semz_fail(c, -1, "null pointer");
     // host-side validation of every span the kernels will touch
     uint64_t out_hi = 0;
+    uint32_t batch_kind = units[0].kind;
     uint32_t fam = units[0].kind <= SEMZ_UNIT_GZIP ? 0 : units[0].kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : 2;
     for (size_t i = 0; i < nunits; i++) {
         const semz_unit &u = units[i];
         uint32_t f = u.kind <= SEMZ_UNIT_GZIP ? 0 : u.kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : 2;
-        if (u.kind > SEMZ_UNIT_LZMA2 || f != fam) return semz_fail(c, -1, "unit %zu: mixed or unknown kind", i);
+        if (u.kind > SEMZ_UNIT_LZMA_WIDE || f != fam) return semz_fail(c, -1, "unit %zu: mixed or unknown kind", i);
+        if (u.kind == SEMZ_UNIT_LZMA_WIDE) batch_kind = SEMZ_UNIT_LZMA_WIDE;
         if (u.in_off > u.in_limit || u.in_limit > in_len) return semz_fail(c, -1, "unit %zu: input span out of range", i);
         if (u.in_bit_off > 7) return semz_fail(c, -1, "unit %zu: bit offset", i);
         if (u.out_off == SEMZ_OUT_AUTO) {
@@ -211,7 +226,7 @@ extern "C" int semz_decode_batch(semz_ctx *c, const uint8_t *in, size_t in_len, 
     HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_units, units, nunits * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(d_res, 0xFF, nunits * sizeof(semz_result), c->stream));
-    rc = semz_decode_batch_device(c, units[0].kind, d_in, in_len, (const semz_unit *)d_units, nunits, d_out, out_hi,
+    rc = semz_decode_batch_device(c, batch_kind, d_in, in_len, (const semz_unit *)d_units, nunits, d_out, out_hi,
                                   (semz_result *)d_res);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(results, d_res, nunits * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));

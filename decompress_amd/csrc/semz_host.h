@@ -24,6 +24,11 @@ struct semz_ctx {
     bool profile = false;
     // :window-size of the :raw-lzma2 format (lzma2.lisp:206-218), semz_set_option "window-size"
     uint64_t window_size = 0xFFFFFFFFull;
+    // keywords of the :raw-lzma format (lzma.lisp:809-825): "lc", "lp", "pb", "decompressed-size" (< 0 = nil),
+    // "eof-mode" (0 :maybe 1 :always 2 :never); "lzma-honour-size": see stream.cpp run_lzma
+    int lz_lc = -1, lz_lp = -1, lz_pb = -1, lz_eof_mode = 0;
+    long long lz_size = -1;
+    bool lz_honour_size = false;
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};
@@ -32,7 +37,7 @@ struct semz_ctx {
 enum {
     SEMZ_SLOT_TAILS = 0, SEMZ_SLOT_IN, SEMZ_SLOT_UNITS, SEMZ_SLOT_OUT, SEMZ_SLOT_RES,
     SEMZ_SLOT_BZ_META, SEMZ_SLOT_BZ_DATA, SEMZ_SLOT_BZ_TT, SEMZ_SLOT_BZ_AUX,
-    SEMZ_SLOT_LZ_META, SEMZ_SLOT_STREAM_A, SEMZ_SLOT_STREAM_B, SEMZ_SLOT_STREAM_C,
+    SEMZ_SLOT_LZ_META, SEMZ_SLOT_LZ_WIDE, SEMZ_SLOT_STREAM_A, SEMZ_SLOT_STREAM_B, SEMZ_SLOT_STREAM_C,
     SEMZ_SLOT_COUNT
 };
 
@@ -52,5 +57,6 @@ void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32
 }
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);
+// wide: literal probabilities in HBM scratch (SEMZ_UNIT_LZMA_WIDE)
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
-                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);
+                   uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide);

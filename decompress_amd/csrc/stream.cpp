@@ -470,6 +470,59 @@ int run_lzma2(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *
     return 0;
 }
 
+// ---- :raw-lzma / :lzma (lzma.lisp:809-865): one unit, no members ----
+// As written, the :lzma constructor hands the header's size on as :expected-remaining-data, a keyword the
+// :raw-lzma method does not have (its name is :decompressed-size, lzma.lisp:811 vs 857): the size reaches the
+// header plist only and the data must end with a marker.  That is the default here; the option
+// "lzma-honour-size" decodes what the code evidently means (declared size, eof-mode :maybe).
+int run_lzma(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *info)
+{
+    semz_unit u{};
+    u.in_limit = R.in_len;
+    uint64_t guess = std::max<uint64_t>(1 << 20, 8 * R.in_len);
+    if (fmt == SEMZ_FMT_LZMA) {
+        if (R.in_len < 1) { oc.status = SEMZ_EOF; return 0; }
+        const uint32_t octet = R.in[0];                      // parse-lzma-props, lzma.lisp:837-843
+        const uint32_t lc = octet % 9, lp = (octet / 9) % 5, pb = octet / 45;
+        if (pb > 4) { oc.status = SEMZ_E_LZMA_PB; oc.detail = pb; oc.consumed = 1; return 0; }
+        if (R.in_len < 13) { oc.status = SEMZ_EOF; oc.consumed = R.in_len; return 0; }
+        uint32_t dict = 0;
+        uint64_t size = 0;
+        for (int i = 0; i < 4; i++) dict |= (uint32_t)R.in[1 + i] << (8 * i);
+        for (int i = 0; i < 8; i++) size |= (uint64_t)R.in[5 + i] << (8 * i);
+        const bool have = size != ~0ull;
+        if (info) {
+            uint32_t *h = info->first_header;                // (:lc :lp :pb :window-size :decompressed-size)
+            h[0] = lc; h[1] = lp; h[2] = pb; h[3] = dict; h[4] = have; h[5] = (uint32_t)size; h[6] = (uint32_t)(size >> 32);
+        }
+        u.in_off = 13;
+        u.param0 = dict;
+        u.param1 = lc | lp << 8 | pb << 16;
+        u.param2 = 0;                                        // :eof-mode :maybe
+        if (have && R.c->lz_honour_size) { u.flags |= SEMZ_UF_HAVE_OUT_SIZE; u.size_out = size; }
+    } else {
+        semz_ctx *c = R.c;
+        if (c->lz_lc < 0 || c->lz_lp < 0 || c->lz_pb < 0)
+            return semz_fail(c, -1, ":raw-lzma needs the options lc, lp, pb and window-size (lzma.lisp:818-821)");
+        u.param0 = (uint32_t)(c->window_size > 0xFFFFFFFFull ? 0xFFFFFFFFull : c->window_size);
+        u.param1 = (uint32_t)c->lz_lc | (uint32_t)c->lz_lp << 8 | (uint32_t)c->lz_pb << 16;
+        u.param2 = (uint32_t)c->lz_eof_mode;
+        if (c->lz_size >= 0) { u.flags |= SEMZ_UF_HAVE_OUT_SIZE; u.size_out = (uint64_t)c->lz_size; }
+    }
+    const uint32_t lclp = (u.param1 & 0xFF) + ((u.param1 >> 8) & 0xFF);
+    u.kind = lclp > 4 ? SEMZ_UNIT_LZMA_WIDE : SEMZ_UNIT_LZMA;
+    if ((u.flags & SEMZ_UF_HAVE_OUT_SIZE) && u.size_out < (1ull << 36)) guess = std::max<uint64_t>(u.size_out, 1);
+    semz_result r{};
+    int rc = R.decode_one(u, r, guess);
+    if (rc) return rc;
+    oc.consumed = (r.in_end_bit + 7) / 8;
+    if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
+    R.emit(r.out_off, r.out_len);
+    if (info) info->nmembers = 1;
+    if (all_members && oc.consumed != R.in_len) oc.status = SEMZ_E_TRAILING_DATA;       // interface.lisp:125-130
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t **out,
@@ -500,6 +553,8 @@ extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_
     }
     case SEMZ_FMT_BZIP2: rc = run_bzip2(R, all_members != 0, oc, &si); break;
     case SEMZ_FMT_XZ: rc = run_xz(R, all_members != 0, oc, &si); break;
+    case SEMZ_FMT_RAW_LZMA:
+    case SEMZ_FMT_LZMA: rc = run_lzma(R, fmt, all_members != 0, oc, &si); break;
     case SEMZ_FMT_RAW_LZMA2:
     case SEMZ_FMT_LZMA2: rc = run_lzma2(R, fmt, all_members != 0, oc, &si); break;
     default: return semz_fail(c, -1, "format %d has no stream decoder yet", fmt);

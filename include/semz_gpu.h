@@ -52,14 +52,20 @@ enum {
     SEMZ_UNIT_GZIP = 2,        /* gzip member: header, deflate, CRC-32 + ISIZE */
     SEMZ_UNIT_BZIP2_BLOCK = 3, /* block whose 48-bit magic starts at (in_off, in_bit_off) */
     SEMZ_UNIT_XZ_BLOCK = 4,    /* LZMA2 payload of an xz block (+ filters, + check) */
-    SEMZ_UNIT_LZMA2 = 5        /* raw LZMA2 chunk sequence */
+    SEMZ_UNIT_LZMA2 = 5,       /* raw LZMA2 chunk sequence */
+    SEMZ_UNIT_LZMA = 6,        /* raw LZMA data (:raw-lzma, lzma.lisp:809-835): range coder start at in_off;
+                                  lc + lp <= 4 (what liblzma writes); wider literal contexts are
+                                  SEMZ_E_UNSUPPORTED here and need the next kind */
+    SEMZ_UNIT_LZMA_WIDE = 7    /* same for any lc <= 8, lp <= 4: the literal coder's probabilities live in
+                                  HBM scratch (6 MiB per unit), several times slower per literal.  A batch that
+                                  holds such a unit, or is submitted under this kind, runs all its units this way */
 };
 
 /* semz_unit.flags */
 enum {
     SEMZ_UF_HAVE_DICT_FN = 1u << 0,  /* zlib: caller has a dictionary function (zlib.lisp:43-44) */
     SEMZ_UF_HAVE_IN_SIZE = 1u << 2,  /* xz: block header declares a compressed size */
-    SEMZ_UF_HAVE_OUT_SIZE = 1u << 3  /* xz: block header declares an uncompressed size */
+    SEMZ_UF_HAVE_OUT_SIZE = 1u << 3  /* xz: block header declares an uncompressed size; lzma: size_out is valid */
 };
 
 /* xz filters that follow LZMA2 when decoding (semz_unit.filters, xz.lisp:311-344) */
@@ -88,9 +94,10 @@ typedef struct semz_unit {
     uint32_t kind;        /* SEMZ_UNIT_* */
     uint32_t flags;       /* SEMZ_UF_* */
     uint32_t in_bit_off;  /* bzip2: bit offset 0..7 (MSB-first) of the magic inside byte in_off */
-    uint32_t param0;      /* deflate: window size (0 = 32768); bzip2: level 1..9; lzma2/xz: dictionary size */
-    uint32_t param1;      /* xz: check type */
-    uint32_t param2;      /* xz: BCJ start offset (xz.lisp:326-331), shared by the BCJ stages of the chain */
+    uint32_t param0;      /* deflate: window size (0 = 32768); bzip2: level 1..9; lzma/lzma2/xz: dictionary size */
+    uint32_t param1;      /* xz: check type; lzma: lc | lp << 8 | pb << 16 */
+    uint32_t param2;      /* xz: BCJ start offset (xz.lisp:326-331), shared by the BCJ stages of the chain;
+                             lzma: eof-mode 0 :maybe, 1 :always, 2 :never (lzma.lisp:575-577, 824-825) */
     uint32_t param3;      /* xz: delta distances minus one, 8 bits per delta stage in chain order */
     uint32_t filters;     /* xz: filter chain applied to the LZMA2 output, 4 bits per stage
                              (SEMZ_FILTER_*), first applied stage in bits 3:0; in the block header
@@ -98,7 +105,7 @@ typedef struct semz_unit {
     uint64_t prefix_off;  /* deflate/zlib preset history: span inside `in` (deflate.lisp:419-425) */
     uint64_t prefix_len;
     uint64_t size_in;     /* xz: declared compressed size (SEMZ_UF_HAVE_IN_SIZE) */
-    uint64_t size_out;    /* xz: declared uncompressed size (SEMZ_UF_HAVE_OUT_SIZE) */
+    uint64_t size_out;    /* xz: declared uncompressed size; lzma: :decompressed-size (SEMZ_UF_HAVE_OUT_SIZE) */
 } semz_unit;
 
 typedef struct semz_result {
@@ -144,7 +151,10 @@ int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, siz
                              void *d_out, size_t out_cap, semz_result *d_results);
 /* Options: "profile" = 1 records a HIP event pair around every kernel of later calls.
  * "window-size" = the :window-size keyword of the :raw-lzma2 format (lzma2.lisp:206-218; values
- * above 2^32-1 are clipped as there), used by semz_decode_stream(SEMZ_FMT_RAW_LZMA2). */
+ * above 2^32-1 are clipped as there), used by semz_decode_stream(SEMZ_FMT_RAW_LZMA2 / _RAW_LZMA).
+ * "lc", "lp", "pb", "decompressed-size" (< 0 = nil), "eof-mode" (0 :maybe, 1 :always, 2 :never) = the
+ * keywords of the :raw-lzma format (lzma.lisp:809-825).  "lzma-honour-size" = 1 makes SEMZ_FMT_LZMA
+ * honour the size its header declares (off = the reference as written). */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */

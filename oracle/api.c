@@ -30,6 +30,7 @@ void orc_decompress(int fmt, const uint8_t *in, size_t in_len, int all_members,
         case 1: { orc_zlib_header h; orc_zlib_member(p, n, 0, NULL, 0, out + outn, out_cap - outn, &h, &r); break; }
         case 2: { orc_gzip_header h; orc_gzip_member(p, n, out + outn, out_cap - outn, &h, &r); break; }
         case 3: orc_bzip2_member(p, n, out + outn, out_cap - outn, &r); break;
+        case 5: { uint32_t hdr[5]; uint64_t hs; orc_lzma_alone(p, n, (int)opt, out + outn, out_cap - outn, hdr, &hs, &r); break; }
         case 6: orc_lzma2(p, n, 0, 0, opt, out + outn, out_cap - outn, &r); break;
         case 7: {                                          /* :lzma2 = dictionary size byte + :raw-lzma2, lzma2.lisp:222-227 */
             memset(&r, 0, sizeof r);

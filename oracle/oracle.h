@@ -92,6 +92,12 @@ void orc_bzip2_member(const uint8_t *in, size_t in_len,
 /* ---- LZMA2 / XZ (lzma.lisp, lzma2.lisp, xz.lisp, xz-bcj-filters.lisp) ---- */
 /* Raw LZMA2 chunk sequence at in[0..limit) (limit = declared compressed size,
  * or in_len when unknown -> have_limit=0). */
+/* :raw-lzma (lzma.lisp:809-835); eof_mode 0 :maybe, 1 :always, 2 :never */
+void orc_lzma(const uint8_t *in, size_t in_len, unsigned lc, unsigned lp, unsigned pb, uint32_t dict_size,
+              int have_size, uint64_t size, int eof_mode, uint8_t *out, size_t out_cap, orc_result *res);
+/* :lzma, the .lzma container (lzma.lisp:837-865); honour_size: see lzma.c */
+void orc_lzma_alone(const uint8_t *in, size_t in_len, int honour_size, uint8_t *out, size_t out_cap,
+                    uint32_t hdr[5], uint64_t *hsize, orc_result *res);
 void orc_lzma2(const uint8_t *in, size_t in_len, int have_limit, uint64_t limit,
                uint32_t dict_size, uint8_t *out, size_t out_cap, orc_result *res);
 /* x86 BCJ inverse in place over a whole block (xz-bcj-filters.lisp:169-219). */

@@ -60,6 +60,10 @@ def lib():
         _lib.orc_bzip2_member.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(OResult)]
         _lib.orc_lzma2.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.c_char_p,
                                    C.c_size_t, C.POINTER(OResult)]
+        _lib.orc_lzma.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, C.c_uint32, C.c_int, C.c_uint64,
+                                  C.c_int, C.c_char_p, C.c_size_t, C.POINTER(OResult)]
+        _lib.orc_lzma_alone.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
+                                        C.POINTER(C.c_uint32 * 5), C.POINTER(C.c_uint64), C.POINTER(OResult)]
         _lib.orc_bcj_x86.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         _lib.orc_bcj_simple.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint]
         _lib.orc_delta.argtypes = [C.c_char_p, C.c_size_t, C.c_uint]
@@ -121,6 +125,20 @@ def lzma2(data, dict_size, limit=None, cap=1 << 22):
                                            limit or 0, dict_size, *a), cap)
 
 
+def lzma1(data, lc, lp, pb, dict_size, size=None, eof_mode=0, cap=1 << 22):
+    """:raw-lzma (lzma.lisp:809-835). eof_mode 0 :maybe 1 :always 2 :never; size = :decompressed-size or None."""
+    return _run(lambda *a: lib().orc_lzma(bytes(data), len(data), lc, lp, pb, dict_size, 0 if size is None else 1,
+                                          size or 0, eof_mode, *a), cap)
+
+
+def lzma_alone(data, honour_size=False, cap=1 << 22):
+    """:lzma, the .lzma container. Returns (result, output, header words [lc, lp, pb, window, have_size], size)."""
+    hdr = (C.c_uint32 * 5)()
+    hsize = C.c_uint64()
+    r, out = _run(lambda *a: lib().orc_lzma_alone(bytes(data), len(data), int(honour_size), *a[:2], C.byref(hdr), C.byref(hsize), a[2]), cap)
+    return r, out, list(hdr), hsize.value
+
+
 def bcj_x86(buf, start=0):
     b = C.create_string_buffer(bytes(buf), len(buf))
     lib().orc_bcj_x86(b, len(buf), start)
@@ -141,5 +159,5 @@ def delta(buf, distance):
 
 
 def decompress(fmt, data, all_members=True, opt=0, cap=1 << 22):
-    """Mirror of decompress / decompress-all. fmt: 0 deflate 1 zlib 2 gzip 3 bzip2 6 raw-lzma2 (opt = window size) 7 lzma2 8 xz."""
+    """Mirror of decompress / decompress-all. fmt: 0 deflate 1 zlib 2 gzip 3 bzip2 5 lzma (opt = 1: honour the declared size) 6 raw-lzma2 (opt = window size) 7 lzma2 8 xz."""
     return _run(lambda *a: lib().orc_decompress(fmt, bytes(data), len(data), int(all_members), opt, *a), cap)

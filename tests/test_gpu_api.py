@@ -89,3 +89,26 @@ def test_lzma2_formats():
     assert e.value.status == 170
     s = api.make_decompression_stream("raw-lzma2", raw, window_size=1 << 16)
     assert s.read() == d
+
+
+def test_lzma_formats():
+    """:lzma reports (:lc :lp :pb :window-size :decompressed-size), lzma.lisp:860-865; :raw-lzma takes them as keywords."""
+    import lzma
+    d = b".lzma through the public interface " * 400
+    a = lzma.compress(d, lzma.FORMAT_ALONE, filters=[{"id": lzma.FILTER_LZMA1, "preset": 1, "lc": 2, "lp": 1, "pb": 0,
+                                                        "dict_size": 1 << 16}])
+    out, header = api.decompress("lzma", a)
+    assert out == d and header == {"lc": 2, "lp": 1, "pb": 0, "window_size": 1 << 16, "decompressed_size": None}
+    out, header = api.decompress("raw-lzma", a[13:], lc=2, lp=1, pb=0, window_size=1 << 16)
+    assert out == d and header is None
+    out, _ = api.decompress("raw-lzma", a[13:], lc=2, lp=1, pb=0, window_size=1 << 16, decompressed_size=len(d),
+                            eof_mode="always")
+    assert out == d
+    with pytest.raises(api.DecompressionError) as e:
+        api.decompress("raw-lzma", a[13:], lc=2, lp=1, pb=0, window_size=1 << 16, eof_mode="never")
+    assert e.value.status == 88
+    with pytest.raises(TypeError):
+        api.decompress("raw-lzma", a[13:], lc=9, lp=1, pb=0, window_size=1 << 16)
+    with pytest.raises(api.EOF):
+        api.decompress("lzma", a[:40])
+    assert {"lzma", "raw-lzma", "lzma2", "raw-lzma2"} <= set(api.list_supported_formats())
