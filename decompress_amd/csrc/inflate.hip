@@ -111,6 +111,9 @@ static_assert(sizeof(UnitLds) <= 10240, "sixteen units per CU");
 
 typedef const __attribute__((address_space(4))) uint32_t *k_u32p;   // scalar-load view of read-only memory
 
+// the lane's bit of a wave-uniform mask as a lane predicate (the mask becomes the condition operand itself)
+__device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+
 template <typename T> __device__ __forceinline__ T uni(T v)           // says: this value is the same in every lane
 {
     if constexpr (sizeof(T) == 8) {
@@ -472,7 +475,6 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
                     const uint32_t e = L.lit_root[lo & ((1u << LIT_ROOT_BITS) - 1)];
                     const uint32_t cl = e & 15;
-                    const bool islit = (e & LIT_FLAG) != 0;
                     const uint32_t lx = (e >> 5) & 7;                          // 0 in literal entries
                     const uint32_t length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(lo, cl, lx);
                     const uint32_t o2 = cl + lx;                               // <= 20
@@ -480,10 +482,13 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
                     const uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
                     const uint32_t distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
+                    // Lane predicates are kept as 64-bit masks in scalar registers and combined there; lane_of() turns a
+                    // mask back into the predicate of a select or a branch without an instruction.
+                    const uint64_t litmask = __builtin_amdgcn_ballot_w64((e & LIT_FLAG) != 0);
                     // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
-                    const bool stop = cl == 0 || (!islit && dl == 0);
-                    const uint32_t tbits = stop ? 64u : (islit ? cl : o2 + dl + dx);
-                    const uint32_t olen = stop ? 0u : (islit ? 1u : length);
+                    const uint64_t stopmask = __builtin_amdgcn_ballot_w64(cl == 0) | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
+                    const bool islit = lane_of(litmask);
+                    const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
                     // the chain of token starts inside the window
                     uint64_t mask = 0;
                     uint32_t off = 0;
@@ -492,25 +497,23 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                         asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(off));       // mask |= 1 << off, one instruction
                         off += t;
                     } while (off < 64);
-                    const bool start = (mask >> lane) & 1;
-                    const bool ismatch = start && !stop && !islit;
-                    const uint32_t ol = start ? olen : 0u;
+                    const uint64_t matchmask = mask & ~(stopmask | litmask);
+                    const uint32_t ol = lane_of(mask & ~stopmask) ? (islit ? 1u : length) : 0u;
                     const uint32_t incl = wave_scan_add(ol);
                     const uint32_t ooff = rbytes + incl - ol;                  // output offset inside the round
-                    const uint64_t matchmask = __builtin_amdgcn_ballot_w64(ismatch);
                     const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
                     {
                         // the usual window: no token for the scalar step, everything fits the round: keep it whole
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         const uint32_t nm = (uint32_t)__builtin_popcountll(matchmask);
                         // (all operands are far below 2^31: one sign test for both limits)
-                        bool whole = (__builtin_amdgcn_ballot_w64(stop) & mask) == 0 && round_ok &&
+                        bool whole = (stopmask & mask) == 0 && round_ok &&
                                      (int32_t)(((uint32_t)ROUND_BYTES - (rbytes + total)) | ((uint32_t)QCAP - (ntok + nm))) >= 0;
-                        if (whole && avail < 32768u) whole = __builtin_amdgcn_ballot_w64(ismatch && distance > avail + ooff) == 0;
+                        if (whole && avail < 32768u) whole = (__builtin_amdgcn_ballot_w64(distance > avail + ooff) & matchmask) == 0;
                         if (whole) {
-                            if (start && islit) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
+                            if (lane_of(mask & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
                             join_lanes();
-                            if (ismatch) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                            if (lane_of(matchmask)) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
                             join_lanes();
                             COUNT(1, (uint32_t)__builtin_popcountll(mask));
                             rbytes += total;
@@ -525,11 +528,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                         }
                     }
                     const uint32_t have = avail + ooff;                        // deflate.lisp:329-331
-                    const bool hard = start && (stop || (ismatch && distance > (have < wsize ? have : wsize)) ||
-                                                (uint64_t)ooff + ol > (uint64_t)room);
-                    const bool soft = start && (ooff >= (uint32_t)ROUND_BYTES || (ismatch && ntok + mrank >= (uint32_t)QCAP));
-                    const uint64_t hardmask = __builtin_amdgcn_ballot_w64(hard);
-                    const uint64_t cutmask = hardmask | __builtin_amdgcn_ballot_w64(soft);
+                    const uint64_t hardmask = mask & (stopmask | (matchmask & __builtin_amdgcn_ballot_w64(distance > (have < wsize ? have : wsize))) |
+                                                      __builtin_amdgcn_ballot_w64((uint64_t)ooff + ol > (uint64_t)room));
+                    const uint64_t softmask = mask & (__builtin_amdgcn_ballot_w64(ooff >= (uint32_t)ROUND_BYTES) |
+                                                      (matchmask & __builtin_amdgcn_ballot_w64(ntok + mrank >= (uint32_t)QCAP)));
+                    const uint64_t cutmask = hardmask | softmask;
                     uint64_t keep = mask;
                     uint32_t adv = off;
                     if (cutmask) {
@@ -541,10 +544,9 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     } else {
                         rbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + ol), 63);
                     }
-                    const bool kept = (keep >> lane) & 1;
-                    if (kept && islit) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
+                    if (lane_of(keep & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
                     join_lanes();
-                    if (kept && !islit) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                    if (lane_of(keep & ~litmask)) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
                     join_lanes();
                     ntok += (uint32_t)__builtin_popcountll(matchmask & keep);
                     COUNT(1, (uint32_t)__builtin_popcountll(keep));
