@@ -490,6 +490,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const bool islit = lane_of(litmask);
                     const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
                     // the chain of token starts inside the window
+                    // gfx950 wants a wait state between the VALU write of tbits and a v_readlane of it; left to itself the
+                    // compiler puts that s_nop at the head of the loop, once per token, instead of here, once per window
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);            // any scalar instruction serves; there is no s_nop builtin
+                    __builtin_amdgcn_sched_barrier(0);
                     uint64_t mask = 0;
                     uint32_t off = 0;
                     do {
