@@ -119,14 +119,18 @@ struct Lz {
     }
     __device__ __forceinline__ uint32_t bit(uint16_t *probs, uint32_t idx)   // lzma.lisp:83-116
     {
+        // selects instead of branches, and the update stored by every lane (same address, same value: one LDS
+        // pass) instead of by lane 0 behind an exec mask: both halve the instructions of the step
         const uint32_t p = uni((uint32_t)probs[idx]);
         const uint32_t bound = p * (range >> 11);
-        uint32_t b, np;
-        if (code >= bound) { range -= bound; code -= bound; np = p - (p >> 5); b = 1; }
-        else { range = bound; np = p + ((2048 - p) >> 5); b = 0; }
-        if ((threadIdx.x & 63) == 0) probs[idx] = (uint16_t)np;
+        const uint32_t r1 = range - bound, c1 = code - bound;
+        const uint32_t p1 = p - (p >> 5), p0 = p + ((2048 - p) >> 5);
+        const bool one = code >= bound;
+        range = one ? r1 : bound;
+        code = one ? c1 : code;
+        probs[idx] = (uint16_t)(one ? p1 : p0);
         normalize();
-        return b;
+        return one ? 1u : 0u;
     }
     // same over probabilities kept in HBM (the literal coder of SEMZ_UNIT_LZMA_WIDE); L2-coherent accesses, so
     // that the wave reads back its own updates
