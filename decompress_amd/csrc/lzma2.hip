@@ -62,51 +62,72 @@ struct __align__(16) LzLds {
 // Wave-uniform decoder state.  Reads go through next_byte(); after the first
 // failure every later read returns 0 and the symbol loops run on until they
 // poll `status`, which keeps the first failure (the one the reference raises).
+// The hot state is small on purpose (every value that a rare branch changes
+// costs a register copy on the common path): a 32-bit offset into a window of
+// the input that is re-based at every chunk, one limit, the current dword.
+constexpr int32_t LZ_PENDING_LIMIT = -100;     // a read ran into `end`: which limit it was is worked out afterwards
+
 struct Lz {
-    // byte source with nested limits (io.lisp:258-323): v-offsets = offset inside `in` + (in & 3)
-    k_u32p base4;
-    uint64_t pos;         // next byte
+    // byte source with nested limits (io.lisp:258-323); positions are v-offsets = offset inside `in` + (in & 3)
+    const uint8_t *in0;   // in - (in & 3): dword aligned
+    uint64_t vbase;       // v-offset of the window (multiple of 4)
+    k_u32p base4;         // scalar-load view of in0 + vbase
+    uint32_t off;         // next byte, relative to vbase
+    uint32_t end;         // min of the three limits, relative to vbase (saturated: see rebase())
+    uint32_t cur;         // unread bytes of the dword that holds byte `off`
     uint64_t phys_end;    // physical end of the input           -> SEMZ_EOF
     uint64_t block_end;   // declared xz compressed size, or ~0  -> SEMZ_E_XZ_BLOCK_OVERRUN
     uint64_t chunk_end;   // LZMA2 chunk compressed size, or ~0  -> SEMZ_E_LZMA2_CHUNK_OVERRUN
-    uint64_t rd_end;      // min of the three
-    uint64_t apos;        // v-offset of the dword cur was taken from (multiple of 4)
-    uint32_t cur;         // unread bytes of that dword
     int32_t status;
     uint32_t detail;
     // range decoder
     uint32_t range, code;
 
-    __device__ __forceinline__ void fail(int st, uint32_t d) { if (status == SEMZ_OK) { status = st; detail = d; } }
-    // cur holds the unread bytes of the dword at apos, already shifted down.  The dword index is kept in
-    // its own variable: were the load address derived from `pos`, the compiler folds "pos is a multiple of
-    // four here" into an s_load from a misaligned base plus a byte offset, and the scalar memory unit drops
-    // the low two bits of the base.
+    __device__ __forceinline__ uint64_t pos() const { return vbase + off; }
+    // written as selects: no control flow, so nothing else is merged behind it
+    __device__ __forceinline__ void fail(int st, uint32_t d)
+    {
+        detail = status == SEMZ_OK ? d : detail;
+        status = status == SEMZ_OK ? st : status;
+    }
+    // cur holds the unread bytes of the dword at `off`, already shifted down
     __device__ __forceinline__ void load_cur()
     {
-        apos = pos & ~3ull;
         cur = 0;
-        if (apos < phys_end) cur = base4[apos >> 2] >> (8 * ((uint32_t)pos & 3));
+        if (off < end) cur = base4[off >> 2] >> (8 * (off & 3));
     }
-    __device__ __forceinline__ void set_limits()
+    // moves the window to `p` and recomputes the limit.  The window is re-based at every LZMA2 chunk (at most
+    // 64 KiB long) and, for raw LZMA, every 2^30 bytes, so a saturated `end` is never reached
+    __device__ __forceinline__ void rebase(uint64_t p)
     {
-        rd_end = phys_end < block_end ? phys_end : block_end;
-        if (chunk_end < rd_end) rd_end = chunk_end;
+        vbase = p & ~3ull;
+        base4 = (k_u32p)(uintptr_t)(in0 + vbase);
+        off = (uint32_t)(p - vbase);
+        uint64_t lim = phys_end < block_end ? phys_end : block_end;
+        if (chunk_end < lim) lim = chunk_end;
+        const uint64_t rel = lim > vbase ? lim - vbase : 0;
+        end = rel < 0xFFFFFFF0ull ? (uint32_t)rel : 0xFFFFFFF0u;
+        load_cur();
+    }
+    __device__ __forceinline__ void set_limits() { rebase(pos()); }
+    // the failure of a read that ran into `end`: the innermost limit that has been reached wins; otherwise the input itself ended
+    __device__ __forceinline__ void resolve_limit()
+    {
+        if (status != LZ_PENDING_LIMIT) return;
+        const uint64_t p = pos();
+        status = p >= chunk_end ? SEMZ_E_LZMA2_CHUNK_OVERRUN : p >= block_end ? SEMZ_E_XZ_BLOCK_OVERRUN : SEMZ_EOF;
+        detail = 0;
     }
     __device__ __forceinline__ uint32_t next_byte()
     {
-        if (pos >= rd_end) {
-            // innermost limit that has been reached wins; otherwise the input itself ended
-            fail(pos >= chunk_end ? SEMZ_E_LZMA2_CHUNK_OVERRUN : pos >= block_end ? SEMZ_E_XZ_BLOCK_OVERRUN : SEMZ_EOF, 0);
+        if (off >= end) {
+            fail(LZ_PENDING_LIMIT, 0);
             return 0;
         }
         const uint32_t b = cur & 0xFF;
         cur >>= 8;
-        pos++;
-        if (((uint32_t)pos & 3) == 0) {
-            apos += 4;
-            if (apos < phys_end) cur = base4[apos >> 2];
-        }
+        off++;
+        if ((off & 3) == 0 && off < end) cur = base4[off >> 2];
         return b;
     }
     __device__ __forceinline__ void normalize()                          // lzma.lisp:64-73
@@ -227,18 +248,17 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
 
     const uint64_t amis = (uint64_t)((uintptr_t)in & 3);
     Lz z;
-    z.base4 = (k_u32p)((uintptr_t)in - amis);
-    z.pos = un.in_off + amis;
+    z.in0 = in - amis;
+    const uint64_t pos0 = un.in_off + amis;
     z.phys_end = un.in_limit + amis;
-    z.block_end = (is_xz && (un.flags & SEMZ_UF_HAVE_IN_SIZE)) ? z.pos + un.size_in : ~0ull;
-    if (z.block_end < z.pos) z.block_end = ~0ull;      // size_in near 2^64: cannot be reached
+    z.block_end = (is_xz && (un.flags & SEMZ_UF_HAVE_IN_SIZE)) ? pos0 + un.size_in : ~0ull;
+    if (z.block_end < pos0) z.block_end = ~0ull;       // size_in near 2^64: cannot be reached
     z.chunk_end = ~0ull;
-    z.set_limits();
     z.status = SEMZ_OK;
     z.detail = 0;
     z.range = 0; z.code = 0;
-    z.load_cur();
-    const uint64_t data_start = z.pos;
+    z.rebase(pos0);
+    const uint64_t data_start = pos0;
 
     // LZMA state variables (lzma-state-vars, lzma.lisp:428-460)
     uint32_t rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, history = 0, total_i = 0;
@@ -336,12 +356,12 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                     dict_base = p;
                 }
                 if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
-                if (z.pos + usize > z.rd_end) {                          // bs-read-sequence with eof-error-p
-                    z.pos = z.rd_end;
+                if (usize > (uint64_t)(z.end - z.off)) {                 // bs-read-sequence with eof-error-p
+                    z.off = z.end;
                     (void)z.next_byte();
                     break;
                 }
-                const uint8_t *src = in + (z.pos - amis);
+                const uint8_t *src = in + (z.pos() - amis);
                 lds_sync();
                 for (uint64_t off = 0; off < usize; off += LZ_FLUSH) {
                     const uint32_t n = usize - off < (uint64_t)LZ_FLUSH ? (uint32_t)(usize - off) : (uint32_t)LZ_FLUSH;
@@ -350,8 +370,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                     lds_sync();
                     flush(false);
                 }
-                z.pos += usize;
-                z.load_cur();
+                z.rebase(z.pos() + usize);
                 if (have_state) total_i = (total_i + (uint32_t)usize) & 15;   // lzma2.lisp:184-188
                 continue;
             }
@@ -373,7 +392,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
             if (control >= 0xE0) dict_base = p;
             if (p + usize > out_cap) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
             // counted source for the chunk (lzma2.lisp:111-116)
-            z.chunk_end = z.pos + csize;
+            z.chunk_end = z.pos() + csize;
             z.set_limits();
             end = p + usize;
             fresh = control >= 0xA0 || !have_state;                  // fresh lzma-state-vars (lzma2.lisp:144-145)
@@ -402,6 +421,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
         bool eofp = false;
         for (;;) {
             if (z.status != SEMZ_OK) break;
+            if (z.off >= 0x40000000u) z.set_limits();                // raw LZMA has no chunks: re-base the input window
             const uint32_t pos_state = total_i & pb_mask;
             if (p == end) {
                 // handle-eof-insanity (lzma.lisp:640-659): :always probes at once, the others ask the range decoder first
@@ -509,7 +529,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
             if (end != ~0ull && p != end) z.fail(SEMZ_E_LZMA_EARLY_END, 0);                 // lzma.lisp:891-894
             break;
         }
-        if (z.pos != z.chunk_end) { z.fail(SEMZ_E_LZMA2_CHUNK_SHORT, 0); break; }   // lzma2.lisp:200-201
+        if (z.pos() != z.chunk_end) { z.fail(SEMZ_E_LZMA2_CHUNK_SHORT, 0); break; }   // lzma2.lisp:200-201
         z.chunk_end = ~0ull;
         z.set_limits();
     }
@@ -519,14 +539,14 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
     // ---- xz block end (xz.lisp:426-457) and results ----
     semz_tail t{};
     semz_result r{};
-    const uint64_t real_csize = z.pos - data_start;
+    z.resolve_limit();
+    const uint64_t real_csize = z.pos() - data_start;
     if (is_xz && z.status == SEMZ_OK) {
         if ((un.flags & SEMZ_UF_HAVE_IN_SIZE) && real_csize != un.size_in) z.fail(SEMZ_E_XZ_BLOCK_SHORT, 0);
         else if ((un.flags & SEMZ_UF_HAVE_OUT_SIZE) && p != un.size_out) z.fail(SEMZ_E_XZ_BLOCK_OUT_SIZE, 0);
         else {
             z.block_end = ~0ull;
             z.set_limits();
-            z.load_cur();
             const uint32_t pad = (4 - ((uint32_t)real_csize & 3)) & 3;
             for (uint32_t k = 0; k < pad && z.status == SEMZ_OK; k++)
                 if (z.next_byte() != 0) z.fail(SEMZ_E_XZ_BLOCK_PADDING, 0);
@@ -535,22 +555,25 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                 const uint32_t cs = ctype == SEMZ_CHECK_CRC32 ? 4 : ctype == SEMZ_CHECK_CRC64 ? 8 : ctype == SEMZ_CHECK_SHA256 ? 32 : 0;
                 t.check_kind = ctype == SEMZ_CHECK_CRC32 ? SEMZ_TK_CRC32 : ctype == SEMZ_CHECK_CRC64 ? SEMZ_TK_CRC64
                                : ctype == SEMZ_CHECK_SHA256 ? SEMZ_TK_SHA256 : SEMZ_TK_NONE;
-                if (z.pos + cs <= z.phys_end) {
+                uint64_t endpos = z.pos();
+                if (endpos + cs <= z.phys_end) {
                     t.have_check = 1;
-                    const uint8_t *cp = in + (z.pos - amis);
+                    const uint8_t *cp = in + (endpos - amis);
                     for (uint32_t k = 0; k < cs / 4; k++) t.want[k] = ld_bytes_le(cp + 4 * k, 4);
-                    z.pos += cs;
+                    endpos += cs;
                 } else {
-                    z.pos = z.phys_end;                              // bs-read-le runs into the end: eof
+                    endpos = z.phys_end;                             // bs-read-le runs into the end: eof
                 }
+                z.rebase(endpos);
             }
         }
     }
-    t.trailer_end_bit = 8 * (z.pos - amis);
+    z.resolve_limit();
+    t.trailer_end_bit = 8 * (z.pos() - amis);
     r.status = z.status;
     r.detail = z.status == SEMZ_OK ? (uint32_t)(real_csize >> 32) : z.detail;
     r.aux = (uint32_t)real_csize;
-    r.in_end_bit = 8 * (z.pos - amis);
+    r.in_end_bit = 8 * (z.pos() - amis);
     r.out_len = p;
     r.out_off = un.out_off;
     if (lane == 0) {
