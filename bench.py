@@ -175,7 +175,7 @@ def main():
                     "(BASELINE configs[2] shape: 512 MiB of the 4 GiB per GPU), block and stream CRCs verified")
     else:
         nunits, unit_bytes = a.units or 16, a.unit_bytes or (16 << 20)
-        a.replicate = a.replicate or 4
+        a.replicate = a.replicate or 8
         workload = (f"{nunits * a.replicate} xz streams of {unit_bytes >> 20} MiB per GPU ({nunits} distinct, each {a.replicate} times), "
                     f"1 MiB LZMA2 blocks + x86 BCJ, check {a.check} verified (BASELINE configs[3] shape)")
     rep = max(1, a.replicate) if a.format in ("bzip2", "xz") else 1

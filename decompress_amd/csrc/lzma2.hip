@@ -28,16 +28,24 @@
 
 namespace {
 
-constexpr int LZ_RING = 8192;
-constexpr int LZ_MASK = LZ_RING - 1;
+// Two sizes of the kernel's LDS state.  SMALL (4 KiB ring, literal table for lc + lp <= 3, which covers what xz
+// writes by default: lc 3, lp 0) is 20,080 bytes, so eight units fit a CU, two per SIMD, and a SIMD with two waves
+// issues twice the instructions of one with a lone wave.  A unit whose properties need the full table leaves the
+// small kernel with LZ_RETRY_FULL and is decoded by the full-size kernel launched right behind it.
+template <bool SMALL> struct LzSize {
+    static constexpr int RING = SMALL ? 4096 : 8192;
+    static constexpr int MASK = RING - 1;
+    static constexpr int LCLP = SMALL ? 3 : 4;
+    static constexpr int TOTAL = 1847 + (0x300 << LCLP) + 1;
+};
+constexpr int32_t LZ_RETRY_FULL = -101;
 constexpr int LZ_FLUSH = 1024;                 // 64 lanes x 16 bytes
 constexpr int MAX_MATCH = 273;                 // +lzma-max-expansion-length+, lzma.lisp:233-238
 
 // probability layout (uint16 indices), lzma.lisp:220-231, 295-313, 428-460
 enum {
     P_IS_LIT = 0, P_IS_SIMPLE = 192, P_USES_REP0 = 204, P_IS_SHORT = 216, P_IS_REP1 = 408, P_IS_REP2 = 420,
-    P_LEN_SIMPLE = 432, P_LEN_REP = 946, P_SLOT = 1460, P_MID = 1716, P_ALIGN = 1831, P_LIT = 1847,
-    P_TOTAL = 1847 + (0x300 << 4) + 1
+    P_LEN_SIMPLE = 432, P_LEN_REP = 946, P_SLOT = 1460, P_MID = 1716, P_ALIGN = 1831, P_LIT = 1847
 };
 enum { LEN_CHOICE = 0, LEN_LOW = 2, LEN_MID = 130, LEN_HIGH = 258 };
 
@@ -54,9 +62,9 @@ template <typename T> __device__ __forceinline__ T uni(T v)
     }
 }
 
-struct __align__(16) LzLds {
-    uint8_t ring[LZ_RING];
-    uint16_t probs[P_TOTAL];
+template <bool SMALL> struct __align__(16) LzLds {
+    uint8_t ring[LzSize<SMALL>::RING];
+    uint16_t probs[LzSize<SMALL>::TOTAL];
 };
 
 // Wave-uniform decoder state.  Reads go through next_byte(); after the first
@@ -221,14 +229,19 @@ enum { EOF_MAYBE = 0, EOF_ALWAYS = 1, EOF_NEVER = 2 };          // eof-mode, lzm
 constexpr uint32_t WIDE_LIT_PROBS = 0x300u << 12;               // lc <= 8, lp <= 4 (lzma.lisp:818-819)
 
 // WIDE: the literal coder's probabilities live in `wide` (WIDE_LIT_PROBS entries per unit) instead of LDS
-template <bool WIDE>
+// SMALL: see LzSize; retry_pass: only the units that the small kernel left with LZ_RETRY_FULL are decoded
+template <bool WIDE, bool SMALL>
 __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                      uint8_t *out, semz_result *results, semz_tail *tails, uint16_t *wide)
+                                                      uint8_t *out, semz_result *results, semz_tail *tails, uint16_t *wide,
+                                                      int retry_pass)
 {
-    __shared__ LzLds L;
+    constexpr int LZ_RING = LzSize<SMALL>::RING, LZ_MASK = LzSize<SMALL>::MASK, P_TOTAL = LzSize<SMALL>::TOTAL;
+    constexpr uint32_t MAX_LCLP = LzSize<SMALL>::LCLP;
+    __shared__ LzLds<SMALL> L;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
+    if (retry_pass && uni(__hip_atomic_load(&results[u].status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != LZ_RETRY_FULL) return;
     semz_unit un;
     {
         k_u32p up = (k_u32p)(uintptr_t)(units + u);
@@ -333,6 +346,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                 z.fail(SEMZ_E_UNSUPPORTED, 2);        // check-type in the reference; wide contexts need SEMZ_UNIT_LZMA_WIDE
                 break;
             }
+            if (!WIDE && nlc + nlp > MAX_LCLP) { z.fail(LZ_RETRY_FULL, 0); break; }
             lc = nlc; lp_mask = (1u << nlp) - 1; pb_mask = (1u << npb) - 1;
             end = (un.flags & SEMZ_UF_HAVE_OUT_SIZE) ? un.size_out : ~0ull;
             cap_end = out_cap;
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                 const uint32_t nlc = octet % 9, nlp = (octet / 9) % 5, npb = octet / 45;
                 if (npb > 4) { z.fail(SEMZ_E_LZMA_PB, npb); break; }
                 if (nlc + nlp > 4) { z.fail(SEMZ_E_LZMA2_LCLP, nlc + nlp); break; }
+                if (!WIDE && nlc + nlp > MAX_LCLP) { z.fail(LZ_RETRY_FULL, 0); break; }
                 lc = nlc; lp_mask = (1u << nlp) - 1; pb_mask = (1u << npb) - 1;
             } else if (!have_state) { z.fail(SEMZ_E_LZMA2_NO_STATE, 0); break; }
             if (control >= 0xE0) dict_base = p;
@@ -809,9 +824,11 @@ int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
         void *w = nullptr;
         int rc = semz_scratch(c, SEMZ_SLOT_LZ_WIDE, (size_t)nunits * WIDE_LIT_PROBS * sizeof(uint16_t), &w);
         if (rc) return rc;
-        lzma2_kernel<true><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, (uint16_t *)w);
+        lzma2_kernel<true, false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, (uint16_t *)w, 0);
     } else {
-        lzma2_kernel<false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr);
+        // eight units per CU; the few units that need the full literal table are redone by the second launch
+        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr, 0);
+        lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr, 1);
     }
     semz_span_end(c);
     // filter chain stages (at most three non-last filters, xz.lisp:262); a kernel returns at once for
