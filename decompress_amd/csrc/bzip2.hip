@@ -125,9 +125,34 @@ struct __align__(16) BzLds {
     uint8_t symbols[256];
     uint16_t count[32];
     uint16_t symq[BZ_QCAP];              // decoded symbols waiting for the MTF wave (ring)
+    uint32_t mtfq[64];                   // the MTF symbols of the consumer's batch, run symbols squeezed out
     int32_t status;
     BzShare sh;
 };
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+
+// sum over the wave, the same value in every lane's scalar view
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 
 // MSB-first bit reader (msb-bit-reader, bits.lisp:121).  Every lane of the
 // wave holds the same state.  The input is staged cooperatively (64 lanes x 16
@@ -433,13 +458,19 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                     }
                 }
                 // the chain of symbol starts inside this window
+                const uint32_t lenv = ev & 31;
                 uint64_t mask = 0;
                 uint32_t off = 0;
                 bool short_input = false;
                 if (endbits - P >= 64 + 20) {
+                    // (a scalar instruction here gives v_readlane the wait state it needs after the VALU write of
+                    // lenv; otherwise the compiler puts an s_nop at the head of the loop, once per symbol)
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
                     do {
-                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)off) & 31;
-                        mask |= 1ull << off;
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)off);
+                        asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(off));       // mask |= 1 << off
                         off += len;
                     } while (off < 64);
                 } else {
@@ -447,7 +478,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                     // longest code of the tree are left (trees are always full-read, huffman.lisp)
                     do {
                         if (endbits - (P + off) < maxlen) { short_input = true; break; }
-                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)ev, (int)off) & 31;
+                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)off);
                         mask |= 1ull << off;
                         off += len;
                     } while (off < 64);
@@ -455,28 +486,28 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                 // group boundary: symbols past it were looked up in the wrong tree
                 uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
                 if (cnt > (uint32_t)BZ_GROUP - k) {
-                    uint64_t rest = mask;
-                    for (uint32_t i = (uint32_t)BZ_GROUP - k; i; i--) rest &= rest - 1;
-                    off = (uint32_t)__builtin_ctzll(rest);
+                    // the start with BZ_GROUP - k starts below it is the first symbol of the next group
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+                    const uint64_t cut = __builtin_amdgcn_ballot_w64(below == (uint32_t)BZ_GROUP - k) & mask;
+                    off = (uint32_t)__builtin_ctzll(cut);
                     mask &= (1ull << off) - 1;
                     cnt = (uint32_t)BZ_GROUP - k;
                     short_input = false;
                 }
                 // end of block
-                const bool start = (mask >> lane) & 1;
-                const uint64_t eobm = __builtin_amdgcn_ballot_w64(start && (ev >> 5) == eob);
+                const uint64_t eobm = __builtin_amdgcn_ballot_w64((ev >> 5) == eob) & mask;
                 uint64_t qmask = mask;
                 bool finished = false;
                 if (eobm) {
                     const uint32_t e = (uint32_t)__builtin_ctzll(eobm);
                     qmask = mask & ((1ull << e) - 1);
-                    off = e + ((uint32_t)__builtin_amdgcn_readlane((int)ev, (int)e) & 31);
+                    off = e + (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)e);
                     finished = true;
                     short_input = false;
                 }
                 // append the symbols to the queue in order and publish them
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(qmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qmask, 0));
-                if ((qmask >> lane) & 1) L.symq[(produced + rank) & (BZ_QCAP - 1)] = (uint16_t)(ev >> 5);
+                if (__builtin_amdgcn_inverse_ballot_w64(qmask)) L.symq[(produced + rank) & (BZ_QCAP - 1)] = (uint16_t)(ev >> 5);
                 produced += (uint32_t)__builtin_popcountll(qmask);
                 k += cnt;
                 P += off;
@@ -513,13 +544,21 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
             // inverse-MTF list: lane i of mtf_a holds entry i < 64; entries 64 .. 255 stay in L.symbols
             uint32_t mtf_a = L.symbols[lane];
             uint32_t ab_len = 0, ab_val = 0, consumed = 0, produced_seen = 0;
-            auto emit_run = [&](uint32_t front, uint32_t run) {
+            // mtfq entry: MTF index (8 bits) | length of the run in front of it << 8 (at most 2^20 - 1), or:
+            constexpr uint32_t CV_LONG = 1u << 31;       // more run digits than +bzip2-ab-bound+
+            constexpr uint32_t RUN_INLINE = 24;          // longer runs are stored by the whole wave, one run at a time
+            // stores `run` copies of `front` at pre[at ..), all lanes
+            auto emit_run = [&](uint32_t at, uint32_t front, uint32_t run) {
                 BZ_COUNT(4);
                 // the counter goes through readfirstlane so that the loop keeps a uniform exit: behind a divergent
                 // exit every scalar that is live across the loop would count as divergent
                 for (uint32_t k0 = 0; k0 < run; k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k0 + 64)))
-                    if (k0 + lane < run) pre[n + k0 + lane] = (uint8_t)front;
-                n += run;
+                    if (k0 + lane < run) pre[at + k0 + lane] = (uint8_t)front;
+                __builtin_amdgcn_wave_barrier();
+            };
+            // lane 0 takes `c0`, lane l > 0 takes lane l - 1 (the DPP shift leaves `old` in lane 0)
+            auto shr1 = [](uint32_t v, uint32_t c0) {
+                return (uint32_t)__builtin_amdgcn_update_dpp((int)c0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             };
             BZ_STAMP(4);
             for (;;) {
@@ -538,66 +577,55 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                 if (m == 0) break;                                       // done and drained
                 const uint32_t sq = (uint32_t)lane < m ? L.symq[(consumed + lane) & (BZ_QCAP - 1)] : 0u;
                 consumed += m;
-                const bool valid = (uint32_t)lane < m;
-                const uint64_t bmask = __builtin_amdgcn_ballot_w64(valid && sq == 1);
-                uint64_t mtfmask = __builtin_amdgcn_ballot_w64(valid && sq >= 2);
+                const uint64_t validm = m == 64 ? ~0ull : (1ull << m) - 1;
+                const uint64_t bmask = __builtin_amdgcn_ballot_w64(sq == 1) & validm;
+                const uint64_t mtfmask = __builtin_amdgcn_ballot_w64(sq >= 2) & validm;
                 BZ_ST(L.sh.consumed, consumed);                          // sq is in registers: the slots are free
-                // MTF symbols with run symbols (or a pending run) right below them
-                const uint64_t runmask = __builtin_amdgcn_ballot_w64(valid && sq < 2);
-                uint64_t afterrun = mtfmask & (runmask << 1);
-                if (ab_len) afterrun |= mtfmask & (0 - mtfmask);
-                bool too_many = false;
-                uint32_t c = 0, outv = 0;            // lane e < c of outv holds the byte of the e-th MTF symbol since the last store
-                // lane 0 takes `c0`, lane l > 0 takes lane l - 1 (the DPP shift leaves `old` in lane 0)
-                auto shr1 = [](uint32_t v, uint32_t c0) {
-                    return (uint32_t)__builtin_amdgcn_update_dpp((int)c0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                };
-                auto move_to_front = [&](uint32_t x, uint32_t idx) {
-                    const uint32_t sh = shr1(mtf_a, x);
-                    mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
-                    outv = (uint32_t)lane == c ? x : outv;
-                    c++;
-                };
-                // stores the pending MTF bytes; an MTF symbol that arrives with the block full is the reference's
-                // failure.  Written without control flow around the scalars: a value merged behind the lane-masked
-                // store would count as divergent and pull the whole walk into VGPRs.
-                auto store_pending = [&]() {
-                    const bool over = n + c > block_size;
-                    too_many |= over;
-                    mtfmask = over ? 0 : mtfmask;
-                    if (!over && (uint32_t)lane < c) pre[n + lane] = (uint8_t)outv;
-                    n += c;
-                    c = 0;
-                    // the optimiser threads the select above into the branches of the store all the same: pin it
-                    mtfmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mtfmask >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mtfmask);
-                };
-                while (mtfmask) {                    // a failure leaves the walk through this condition
-                    const uint32_t i = (uint32_t)__builtin_ctzll(mtfmask);
-                    mtfmask &= ~(1ull << i);
-                    if ((afterrun >> i) & 1) {
-                        store_pending();
-                        // the run symbols [lastpos, i) sit between the MTF symbol before and this one
-                        const uint64_t below = ~runmask & ((1ull << i) - 1);
-                        const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
-                        const uint32_t rl = i - lastpos;
-                        ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
-                        ab_len += rl;
-                        const uint32_t run = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ab_val | (1u << (ab_len & 31))) - 1));
-                        if (too_many) { }
-                        else if (ab_len > (uint32_t)BZ_AB_BOUND) { err = SEMZ_E_BZ_AB_RUN_LENGTH; mtfmask = 0; }
-                        else if (n + run > block_size) { err = SEMZ_E_BZ_AB_RUN_SIZE; mtfmask = 0; }
-                        else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
-                        ab_len = 0;
-                        ab_val = 0;
-                    }
-                    // move-to-front of entry idx >= 1 (after a failure this still runs once, harmlessly)
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)sq, (int)i) - 1;
+                const uint32_t cnt = (uint32_t)__builtin_popcountll(mtfmask);
+                // Every lane with an MTF symbol works out the run that ends right below it inside this batch: the
+                // run symbols between the MTF symbol before it (position lastpos - 1) and itself are the digits of
+                // the run length, RUNB digits straight out of the ballot (bzip2.lisp:221-243).
+                const uint64_t lt = (1ull << lane) - 1;
+                const uint64_t below = mtfmask & lt;
+                const uint32_t lastpos = below ? 64u - (uint32_t)__builtin_clzll(below) : 0u;
+                const uint32_t rl = (uint32_t)lane - lastpos;
+                const uint32_t digits = (uint32_t)(bmask >> lastpos) & ((1u << (rl & 31)) - 1);
+                const uint32_t runv = rl == 0 ? 0u : rl > (uint32_t)BZ_AB_BOUND ? CV_LONG : ((digits | (1u << rl)) - 1) << 8;
+                // the MTF symbols squeezed together: lane e gets the e-th of them
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mtfmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mtfmask, 0));
+                lds_sync();
+                if (__builtin_amdgcn_inverse_ballot_w64(mtfmask)) L.mtfq[rank] = (sq - 1) | runv;
+                __builtin_amdgcn_wave_barrier();
+                lds_sync();
+                const uint32_t cv = (uint32_t)lane < cnt ? L.mtfq[lane] : 0u;
+                uint32_t run = (cv >> 8) & 0x1FFFFFu;
+                bool toolong = (cv & CV_LONG) != 0;
+                // the first MTF symbol also ends the run that was pending from the batches before
+                if (cnt && ab_len) {
+                    const uint32_t i0 = (uint32_t)__builtin_ctzll(mtfmask);
+                    ab_val |= ((uint32_t)bmask & ((1u << i0) - 1)) << (ab_len & 31);
+                    ab_len += i0;
+                    const bool long0 = ab_len > (uint32_t)BZ_AB_BOUND;
+                    const uint32_t run0 = long0 ? 0u : (ab_val | (1u << (ab_len & 31))) - 1;
+                    ab_len = 0;
+                    ab_val = 0;
+                    run = lane == 0 ? run0 : run;
+                    toolong = lane == 0 ? long0 : toolong;
+                }
+                // ---- the MTF walk proper: nothing but the list.  A run repeats the byte in front of the list, which
+                // is the byte of the MTF symbol before it, so runs need no place in the walk: they are laid out
+                // afterwards by all lanes.  x of the e-th symbol collects in lane e of xv.
+                const uint32_t front0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a);
+                const uint32_t idxv = cv & 0xFF;
+                uint32_t xv = 0;
+                for (uint32_t e = 0; e < cnt; e++) {
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
+                    uint32_t x;
                     if (idx < 64) {
-                        move_to_front((uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx), idx);
+                        x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
                     } else {
                         // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
-                        const uint32_t x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
+                        x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
                         uint32_t v[3];
                         for (int c3 = 0; c3 < 3; c3++) {
                             const uint32_t p = 64 + 64 * c3 + lane;
@@ -609,21 +637,53 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                             if (p < idx && p < 255) L.symbols[p + 1] = (uint8_t)v[c3];
                         }
                         if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
+                        __builtin_amdgcn_wave_barrier();
                         lds_sync();
-                        move_to_front(x, idx);
+                    }
+                    const uint32_t sh = shr1(mtf_a, x);
+                    mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;          // an index of 64 and more shifts every lane
+                    xv = (uint32_t)lane == e ? x : xv;
+                }
+                // ---- layout: symbol e puts its run, then its byte
+                const bool live = (uint32_t)lane < cnt;
+                const uint32_t incl = wave_scan_add(live ? 1u + run : 0u);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t xpos = n + incl - 1;                      // where the symbol's own byte goes
+                // failures, first in stream order: run digits, run size, then a symbol that arrives with the block full
+                const uint64_t longm = __builtin_amdgcn_ballot_w64(live && toolong);
+                if (longm || n + total > block_size) {
+                    const uint64_t sizem = __builtin_amdgcn_ballot_w64(live && run && xpos > block_size);
+                    const uint64_t fullm = __builtin_amdgcn_ballot_w64(live && xpos >= block_size);
+                    const uint64_t anym = longm | sizem | fullm;
+                    if (anym) {
+                        const uint64_t first = anym & (0 - anym);
+                        err = (longm & first) ? SEMZ_E_BZ_AB_RUN_LENGTH : (sizem & first) ? SEMZ_E_BZ_AB_RUN_SIZE : SEMZ_E_BZ_TOO_MANY_CODES;
+                        break;
                     }
                 }
-                store_pending();
-                if (err == SEMZ_OK && too_many) err = SEMZ_E_BZ_TOO_MANY_CODES;    // a run failure came first if there is one
-                if (err == SEMZ_OK) {
+                // ---- stores
+                const uint32_t prevx = shr1(xv, front0);
+                if (live) pre[xpos] = (uint8_t)xv;
+                const bool inl = live && run <= RUN_INLINE;
+                for (uint32_t k = 0; __builtin_amdgcn_ballot_w64(inl && k < run); k = (uint32_t)__builtin_amdgcn_readfirstlane((int)(k + 1)))
+                    if (inl && k < run) pre[xpos - run + k] = (uint8_t)prevx;
+                __builtin_amdgcn_wave_barrier();
+                uint64_t bigm = __builtin_amdgcn_ballot_w64(live && run > RUN_INLINE);
+                while (bigm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(bigm);
+                    bigm &= bigm - 1;
+                    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)run, (int)j);
+                    emit_run((uint32_t)__builtin_amdgcn_readlane((int)xpos, (int)j) - r, (uint32_t)__builtin_amdgcn_readlane((int)prevx, (int)j), r);
+                }
+                n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(n + total));
+                {
                     // run symbols at the end of the batch stay pending
-                    const uint64_t below = ~runmask & (m == 64 ? ~0ull : (1ull << m) - 1);
-                    const uint32_t lastpos = below ? 64 - (uint32_t)__builtin_clzll(below) : 0;
-                    const uint32_t rl = m - lastpos;
-                    if (ab_len + rl > (uint32_t)BZ_AB_BOUND) err = SEMZ_E_BZ_AB_RUN_LENGTH;
-                    else if (rl) {
-                        ab_val |= ((uint32_t)(bmask >> lastpos) & ((1u << rl) - 1)) << ab_len;
-                        ab_len += rl;
+                    const uint32_t lp = mtfmask ? 64 - (uint32_t)__builtin_clzll(mtfmask) : 0;
+                    const uint32_t rl2 = m - lp;
+                    if (ab_len + rl2 > (uint32_t)BZ_AB_BOUND) err = SEMZ_E_BZ_AB_RUN_LENGTH;
+                    else if (rl2) {
+                        ab_val |= ((uint32_t)(bmask >> lp) & ((1u << rl2) - 1)) << ab_len;
+                        ab_len += rl2;
                     }
                 }
                 BZ_STAMP(2);
@@ -635,7 +695,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                 // the run in front of the end-of-block symbol
                 const uint32_t run = (ab_val | (1u << ab_len)) - 1;
                 if (n + run > block_size) err = SEMZ_E_BZ_AB_RUN_SIZE;
-                else emit_run((uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run);
+                else { emit_run(n, (uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a), run); n += run; }
             }
         }
         // `done` has been seen: the producer's fields are final
