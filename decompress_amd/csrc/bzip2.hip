@@ -35,6 +35,8 @@ constexpr int BZ_GROUP = 50;                   // symbols per selector (bzip2.li
 constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:217-219
 constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
 constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
+// the walk keeps the first 4 S bytes of every chain (S = marker spacing) in a row of its own: (n / S + 2) rows
+constexpr size_t BZ_TEMP_STRIDE = 4 * (size_t)900032 + 16384;
 constexpr int BWT_THREADS = 512;               // bz_bwt_kernel: three workgroups fit a CU (49 KB of LDS each), so a
 constexpr int BWT_WAVES = BWT_THREADS / 64;    // 600-block batch is resident at once instead of in two rounds
 
@@ -742,7 +744,7 @@ __device__ __forceinline__ uint32_t rle1_step(Rle1 &s, uint32_t b, uint32_t &out
 }
 
 __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz_meta *meta, const uint8_t *pre_all,
-                                                      uint32_t *tt_all, uint8_t *post_all, bz_seg *seg_all)
+                                                      uint32_t *tt_all, uint8_t *post_all, bz_seg *seg_all, uint8_t *temp_all)
 {
     extern __shared__ __align__(16) uint32_t smem[];
     const uint32_t u = blockIdx.x;
@@ -754,6 +756,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     uint32_t *tt = tt_all + (size_t)u * BZ_STRIDE;
     uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
     bz_seg *segs = seg_all + (size_t)u * BZ_SEGS;
+    uint8_t *temp = temp_all + (size_t)u * BZ_TEMP_STRIDE;
 
 #ifdef SEMZ_STAMPS
     uint64_t w_last = __builtin_amdgcn_s_memtime();
@@ -823,9 +826,15 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     const uint32_t nmark = nreg + 1;
     const uint32_t orig = m.orig;
     for (uint32_t i = tid; i < nmark; i += BWT_THREADS) seg_off[i] = 0xFFFFFFFFu;
+    // The walk costs one random 4-byte read (a whole HBM line) per output byte and it is what bounds this kernel,
+    // so it is done once: while a chain is measured its bytes go to the chain's own row of `temp` (4 S bytes; chain
+    // lengths are spread geometrically around S, 2 % are longer), and once the chains are linked the rows are
+    // copied to their places with coalesced accesses.  Only the chains longer than a row are walked a second time.
+    const uint32_t CAP = 4 * S;
     if (n) {
         for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
-            uint32_t k[4], len[4];
+            uint32_t k[4], len[4], acc[4];
+            uint32_t *row[4];
             bool act[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
@@ -833,6 +842,8 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
                 act[c] = id < nmark;
                 k[c] = id == 0 ? orig : (id - 1) * S;
                 len[c] = 0;
+                acc[c] = 0;
+                row[c] = reinterpret_cast<uint32_t *>(temp + (size_t)id * CAP);
             }
             bool any = true;
             while (any) {
@@ -840,11 +851,18 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     if (!act[c]) continue;
-                    uint32_t nk = tt[k[c]] >> 8;
+                    const uint32_t v = tt[k[c]];
+                    if (len[c] < CAP) {
+                        acc[c] |= (v & 0xFF) << (8 * (len[c] & 3));
+                        if ((len[c] & 3) == 3) { row[c][len[c] >> 2] = acc[c]; acc[c] = 0; }
+                    }
+                    const uint32_t nk = v >> 8;
                     len[c]++;
                     k[c] = nk;
-                    if (nk == orig || (nk & (S - 1)) == 0) act[c] = false;
-                    else any = true;
+                    if (nk == orig || (nk & (S - 1)) == 0) {
+                        act[c] = false;
+                        if (len[c] <= CAP && (len[c] & 3)) row[c][len[c] >> 2] = acc[c];
+                    } else any = true;
                 }
             }
 #pragma unroll
@@ -857,6 +875,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
             }
         }
     }
+    __threadfence_block();
     __syncthreads();
     BWT_STAMP(1);
     if (tid == 0) {
@@ -873,6 +892,17 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     const uint32_t cyc = misc[0];
     const uint32_t wlim = cyc < n ? cyc : n;
     if (n) {
+        // rows to their places, one chain per wave at a time
+        for (uint32_t id = wave; id < nmark; id += BWT_WAVES) {
+            const uint32_t so = seg_off[id];
+            if (so == 0xFFFFFFFFu) continue;
+            uint32_t ln = seg_len[id];
+            if (ln > CAP) continue;
+            if (so + ln > wlim) ln = so < wlim ? wlim - so : 0;
+            const uint8_t *src = temp + (size_t)id * CAP;
+            for (uint32_t j = lane; j < ln; j += 64) post[so + j] = src[j];
+        }
+        // the long chains again, straight to their places
         for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
             uint32_t k[4], o[4], e[4];
             bool act[4];
@@ -880,7 +910,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 uint32_t id = id0 + c * BWT_THREADS;
-                act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu;
+                act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu && seg_len[id] > CAP;
                 k[c] = id == 0 ? orig : (id - 1) * S;
                 o[c] = act[c] ? seg_off[id] : 0;
                 e[c] = act[c] ? o[c] + seg_len[id] : 0;
@@ -1115,7 +1145,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     int rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_META, (size_t)nunits * sizeof(bz_meta), &meta))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_DATA, (size_t)nunits * BZ_STRIDE * 2, &pre))) return rc;
-    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_TT, (size_t)nunits * BZ_STRIDE * sizeof(uint32_t), &tt))) return rc;
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_TT, (size_t)nunits * (BZ_STRIDE * sizeof(uint32_t) + BZ_TEMP_STRIDE), &tt))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * BZ_SEGS * sizeof(bz_seg), &segs))) return rc;
     post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
     const size_t smem = (3 * (BZ_CHAINS + 1) + 16) * sizeof(uint32_t);
@@ -1130,7 +1160,8 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     semz_span_end(c);
     semz_span_begin(c, "bz_bwt_kernel");
     bz_bwt_kernel<<<nunits, BWT_THREADS, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,
-                                                     (uint8_t *)post, (bz_seg *)segs);
+                                                     (uint8_t *)post, (bz_seg *)segs,
+                                                     (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t));
     semz_span_end(c);
     semz_span_begin(c, "bz_offsets_kernel");
     bz_offsets_kernel<<<1, 64, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);
