@@ -620,31 +620,42 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                 const uint32_t front0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)mtf_a);
                 const uint32_t idxv = cv & 0xFF;
                 uint32_t xv = 0;
-                for (uint32_t e = 0; e < cnt; e++) {
-                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
-                    uint32_t x;
-                    if (idx < 64) {
-                        x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
-                    } else {
-                        // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
-                        x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
-                        uint32_t v[3];
-                        for (int c3 = 0; c3 < 3; c3++) {
-                            const uint32_t p = 64 + 64 * c3 + lane;
-                            v[c3] = p < idx ? L.symbols[p] : 0u;
-                        }
-                        lds_sync();
-                        for (int c3 = 0; c3 < 3; c3++) {
-                            const uint32_t p = 64 + 64 * c3 + lane;
-                            if (p < idx && p < 255) L.symbols[p + 1] = (uint8_t)v[c3];
-                        }
-                        if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
-                        __builtin_amdgcn_wave_barrier();
-                        lds_sync();
+                if (__builtin_amdgcn_ballot_w64(idxv >= 64) == 0) {
+                    // every index of the batch lies inside the register: a loop without any other path
+                    for (uint32_t e = 0; e < cnt; e++) {
+                        const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
+                        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
+                        const uint32_t sh = shr1(mtf_a, x);
+                        mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
+                        xv = (uint32_t)lane == e ? x : xv;
                     }
-                    const uint32_t sh = shr1(mtf_a, x);
-                    mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;          // an index of 64 and more shifts every lane
-                    xv = (uint32_t)lane == e ? x : xv;
+                } else {
+                    for (uint32_t e = 0; e < cnt; e++) {
+                        const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
+                        uint32_t x;
+                        if (idx < 64) {
+                            x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
+                        } else {
+                            // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
+                            x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
+                            uint32_t v[3];
+                            for (int c3 = 0; c3 < 3; c3++) {
+                                const uint32_t p = 64 + 64 * c3 + lane;
+                                v[c3] = p < idx ? L.symbols[p] : 0u;
+                            }
+                            lds_sync();
+                            for (int c3 = 0; c3 < 3; c3++) {
+                                const uint32_t p = 64 + 64 * c3 + lane;
+                                if (p < idx && p < 255) L.symbols[p + 1] = (uint8_t)v[c3];
+                            }
+                            if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
+                            __builtin_amdgcn_wave_barrier();
+                            lds_sync();
+                        }
+                        const uint32_t sh = shr1(mtf_a, x);
+                        mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;      // an index of 64 and more shifts every lane
+                        xv = (uint32_t)lane == e ? x : xv;
+                    }
                 }
                 // ---- layout: symbol e puts its run, then its byte
                 const bool live = (uint32_t)lane < cnt;
