@@ -490,18 +490,22 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const bool islit = lane_of(litmask);
                     const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
                     // the chain of token starts inside the window
-                    // gfx950 wants a wait state between the VALU write of tbits and a v_readlane of it; left to itself the
-                    // compiler puts that s_nop at the head of the loop, once per token, instead of here, once per window
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(0);            // any scalar instruction serves; there is no s_nop builtin
-                    __builtin_amdgcn_sched_barrier(0);
+                    // The loop is four instructions per token, written out because the compiler has no way to branch
+                    // on the carry of a scalar add: `off` runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only
+                    // look at its low six bits), so the add carries out exactly when the chain leaves the window.
+                    // The s_nop is the wait state gfx950 wants between the VALU write of tbits and a v_readlane of it.
                     uint64_t mask = 0;
-                    uint32_t off = 0;
-                    do {
-                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tbits, (int)off);
-                        asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(off));       // mask |= 1 << off, one instruction
-                        off += t;
-                    } while (off < 64);
+                    uint32_t offb = 0u - 64u, tlen;
+                    asm volatile("s_nop 0\n"
+                                 "1:\n\t"
+                                 "v_readlane_b32 %[t], %[tb], %[off]\n\t"
+                                 "s_bitset1_b64 %[m], %[off]\n\t"
+                                 "s_add_u32 %[off], %[off], %[t]\n\t"
+                                 "s_cbranch_scc0 1b"
+                                 : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen)
+                                 : [tb] "v"(tbits)
+                                 : "scc");
+                    const uint32_t off = offb + 64u;
                     const uint64_t matchmask = mask & ~(stopmask | litmask);
                     const uint32_t ol = lane_of(mask & ~stopmask) ? (islit ? 1u : length) : 0u;
                     const uint32_t incl = wave_scan_add(ol);
