@@ -465,16 +465,22 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
                 uint32_t off = 0;
                 bool short_input = false;
                 if (endbits - P >= 64 + 20) {
-                    // (a scalar instruction here gives v_readlane the wait state it needs after the VALU write of
-                    // lenv; otherwise the compiler puts an s_nop at the head of the loop, once per symbol)
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    do {
-                        const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)off);
-                        asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(off));       // mask |= 1 << off
-                        off += len;
-                    } while (off < 64);
+                    // Four instructions per symbol, written out because the compiler cannot branch on the carry of
+                    // a scalar add: the offset runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only look at
+                    // its low six bits), so the add carries out exactly when the chain leaves the window.  Every
+                    // lane holds a length of at least 1: the trees are complete (bz_build_tree).  The s_nop is the
+                    // wait state gfx950 wants between the VALU write of lenv and a v_readlane of it.
+                    uint32_t offb = 0u - 64u, len;
+                    asm volatile("s_nop 0\n"
+                                 "1:\n\t"
+                                 "v_readlane_b32 %[t], %[tb], %[off]\n\t"
+                                 "s_bitset1_b64 %[m], %[off]\n\t"
+                                 "s_add_u32 %[off], %[off], %[t]\n\t"
+                                 "s_cbranch_scc0 1b"
+                                 : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(len)
+                                 : [tb] "v"(lenv)
+                                 : "scc");
+                    off = offb + 64u;
                 } else {
                     // the last bits of the input: the reference runs out of data when fewer bits than the
                     // longest code of the tree are left (trees are always full-read, huffman.lisp)
