@@ -25,6 +25,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# what the SQ counters (profiles/r01_*_pmc_sq.txt) say bounds the dominant kernel in practice
+ISSUE_NOTES = {
+    "gzip": "instruction-issue bound: scalar pipe 71 %, vector pipe 62 % of their issue rate (profiles/r01_gzip_pmc_sq.txt)",
+    "zlib": "instruction-issue bound like gzip, plus per-record table builds",
+    "bzip2": "bz_bwt_kernel: one random HBM line per output byte, 87 % of wave cycles waiting on memory; bz_decode_kernel: latency of two serial waves per block",
+    "xz": "serial range decoder: 25 instructions and one LDS round trip per bit, two waves per SIMD",
+}
 METRIC = "decompressed GB/s (node) batched gzip/bzip2 blocks @1/2/4/8 GPUs; % HBM peak"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -283,7 +290,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": total_in + total_out,
                          "kernel_ms_avg": round(kavg, 4),
-                         "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname}},
+                         "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname},
+                         "note": ISSUE_NOTES.get(a.format)},
         }
         if not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(a.format, blobs, W["sample_out"])
