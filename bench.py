@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--unit-bytes", type=int, default=0)
     ap.add_argument("--check", default="crc64", choices=["crc64", "sha256", "crc32", "none"])
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer (PCIe-inclusive) call")
     ap.add_argument("--workers", type=int, default=0,
                     help="corpus generation processes (default: the CPU share); 1 = no child processes at all, "
                          "which is what a run under rocprofv3 --pmc wants: pool workers forked under the profiler "
@@ -293,6 +294,23 @@ def main():
                          "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname},
                          "note": ISSUE_NOTES.get(a.format)},
         }
+        if a.format in ("gzip", "bzip2", "xz") and not a.no_e2e:
+            # the drop-in call on host buffers (pageable): split on the host, upload, kernels, download
+            fmt_id = {"gzip": _lib.FMT_GZIP, "bzip2": _lib.FMT_BZIP2, "xz": _lib.FMT_XZ}[a.format]
+            def c_call():                                   # the C ABI itself, as a Lisp host would call it through CFFI
+                out, n, r, si = C.c_void_p(), C.c_size_t(), _lib.Result(), _lib.StreamInfo()
+                t1 = time.perf_counter()
+                rc = eng.lib.semz_decode_stream(eng.h, fmt_id, data, len(data), 1, C.byref(out), C.byref(n), C.byref(r), C.byref(si))
+                dt1 = time.perf_counter() - t1
+                if out.value:
+                    eng.lib.semz_free(out)
+                if rc != 0 or r.status != 0 or n.value != total_out:
+                    raise SystemExit(f"semz_decode_stream: rc {rc}, status {r.status}, {n.value} bytes")
+                return dt1
+            c_call()                                        # grows the context's scratch
+            e2e = min(c_call(), c_call())
+            line["end_to_end"] = {"value": round(total_out / e2e / 1e9, 3), "unit": "GB/s", "ms": round(e2e * 1e3, 2),
+                                  "path": "one semz_decode_stream call on pageable host buffers: host split, H2D, kernels, D2H into a fresh buffer; never `value`"}
         if not a.no_cpu:
             line["cpu_baseline"] = cpu_baseline(a.format, blobs, W["sample_out"])
         print(json.dumps(line), flush=True)

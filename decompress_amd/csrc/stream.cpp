@@ -12,6 +12,9 @@
 // false magic) is decoded on demand as a batch of one.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <sys/mman.h>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -123,7 +126,13 @@ struct Run {
     {
         size_t total = 0;
         for (auto &s : spans) total += s.len;
-        uint8_t *h = (uint8_t *)malloc(total ? total : 1);
+        // large results: 2 MiB alignment and a huge-page hint, so that the first touch of a fresh gigabyte does not
+        // cost a page fault per 4 KiB (the download is otherwise bound by them); still released with free()
+        uint8_t *h;
+        if (total >= (8u << 20)) {
+            h = (uint8_t *)aligned_alloc(2u << 20, (total + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+            if (h) madvise(h, total, MADV_HUGEPAGE);
+        } else h = (uint8_t *)malloc(total ? total : 1);
         if (!h) return semz_fail(c, -5, "out of host memory (%zu bytes)", total);
         size_t at = 0;
         for (auto &s : spans) {
@@ -166,6 +175,56 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
             R.out_used += total;
         }
         free(su);
+        if (pre.empty()) {
+            // Plain concatenated members (pigz, cat of .gz files) carry no index: a member's end is only known
+            // once it is decoded.  So every place that looks like a member header (1F 8B 08, reserved flag bits
+            // clear) is taken as a candidate and all candidates are decoded in one batch, on the hypothesis that
+            // the next candidate is the next member: then the four bytes in front of it are this member's ISIZE,
+            // which sizes its output span.  The forward walk below (interface.lisp:91-133) only uses the result
+            // of a candidate it actually reaches, and only if its span was large enough; everything else (a
+            // look-alike inside compressed data, a member followed by one) is decoded again, alone.
+            std::vector<uint64_t> cand;
+            const uint8_t *in = R.in;
+            for (uint64_t p = 0; p + 18 <= R.in_len; p++) {
+                const void *hit = memchr(in + p, 0x1F, R.in_len - 17 - p);
+                if (!hit) break;
+                p = (uint64_t)((const uint8_t *)hit - in);
+                if (in[p + 1] == 0x8B && in[p + 2] == 8 && in[p + 3] < 0x20) cand.push_back(p);
+            }
+            if (cand.size() >= 2 && cand[0] == 0) {
+                std::vector<semz_unit> units;
+                uint64_t total = 0;
+                for (size_t i = 0; i < cand.size(); i++) {
+                    const uint64_t next = i + 1 < cand.size() ? cand[i + 1] : R.in_len;
+                    const uint64_t span = next - cand[i];
+                    if (span < 18) continue;
+                    const uint64_t isize = (uint64_t)in[next - 4] | (uint64_t)in[next - 3] << 8 | (uint64_t)in[next - 2] << 16 |
+                                           (uint64_t)in[next - 1] << 24;
+                    if (isize > 1032 * span) continue;               // deflate cannot expand further: not a member end
+                    semz_unit u{};
+                    u.kind = SEMZ_UNIT_GZIP;
+                    u.in_off = cand[i];
+                    u.in_limit = R.in_len;
+                    u.out_off = total;
+                    u.out_cap = isize;
+                    total += (isize + 15) & ~15ull;
+                    units.push_back(u);
+                }
+                if (units.size() >= 2) {
+                    int rc = R.reserve(total);
+                    if (rc) return rc;
+                    std::vector<semz_result> res;
+                    rc = R.decode(units, res, R.out_used, total);
+                    if (rc) return rc;
+                    for (size_t i = 0; i < units.size(); i++) {
+                        if (res[i].status == SEMZ_E_OUT_CAP) continue;        // the hypothesis did not hold
+                        res[i].out_off += R.out_used;
+                        pre[units[i].in_off] = res[i];
+                    }
+                    R.out_used += total;
+                }
+            }
+        }
     }
     uint64_t pos = 0;
     for (uint32_t member = 0;; member++) {
@@ -535,9 +594,14 @@ extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_
     memset(res, 0, sizeof *res);
     semz_stream_info si;
     memset(&si, 0, sizeof si);
+    // SEMZ_TRACE=1 prints where the call's wall time goes (upload, split + kernels, download)
+    const bool trace = getenv("SEMZ_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     Run R{c, in, in_len};
     int rc = R.open();
     if (rc) return rc;
+    const double t1 = now();
     Outcome oc;
     switch (fmt) {
     case SEMZ_FMT_DEFLATE:
@@ -560,8 +624,10 @@ extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_
     default: return semz_fail(c, -1, "format %d has no stream decoder yet", fmt);
     }
     if (rc) return rc;
+    const double t2 = now();
     rc = R.gather(out, out_len);
     if (rc) return rc;
+    if (trace) fprintf(stderr, "semz_decode_stream: open+upload %.1f ms, split+decode %.1f ms, download %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
     res->status = oc.status;
     res->detail = oc.detail;
     res->in_end_bit = 8 * oc.consumed;
