@@ -2,6 +2,8 @@
 // without decoding it (include/semz_gpu.h semz_split).
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include "container.h"
 
 namespace semz {
@@ -104,33 +106,55 @@ int parse_bzip2_header(const uint8_t *in, uint64_t pos, uint64_t in_len, uint32_
 
 std::vector<BzCandidate> scan_bzip2(const uint8_t *in, uint64_t in_len)
 {
+    // A 64 Ki-entry filter on the last two bytes of the window rejects 99 % of the positions before the eight
+    // shifted 48-bit compares; the input is scanned in slices by a few host threads.
+    static uint8_t maybe[65536];
+    static bool ready = false;
+    if (!ready) {
+        for (unsigned s = 0; s < 8; s++)
+            for (uint64_t magic : {BZ_BLOCK_MAGIC, BZ_FOOTER_MAGIC})
+                for (unsigned low = 0; low < (1u << s); low++)
+                    maybe[(uint16_t)((magic << s) | low)] = 1;
+        ready = true;
+    }
+    const unsigned nthreads = in_len >= (8u << 20) ? 8 : 1;
+    std::vector<std::vector<BzCandidate>> parts(nthreads);
+    auto scan = [&](unsigned t) {
+        const uint64_t lo = in_len * t / nthreads, hi = in_len * (t + 1) / nthreads;
+        std::vector<BzCandidate> &out = parts[t];
+        for (uint64_t i = lo < 5 ? 5 : lo; i < hi; i++) {
+            if (!maybe[(uint16_t)((uint32_t)in[i - 1] << 8 | in[i])]) continue;
+            uint64_t w = 0;                                   // bytes i-7..i, big-endian (zero before the start)
+            for (int k = 7; k >= 0; k--) w = (w << 8) | (i >= (uint64_t)k ? in[i - k] : 0);
+            // a 48-bit pattern that ends s bits (0..7) before the end of byte i; higher s first = lower bit position
+            for (int s = 7; s >= 0; s--) {
+                const uint64_t v = (w >> s) & 0xFFFFFFFFFFFFull;
+                if (v != BZ_BLOCK_MAGIC && v != BZ_FOOTER_MAGIC) continue;
+                if (i < 6 && s != 0) continue;                // needs 7 bytes unless byte aligned
+                out.push_back(BzCandidate{8 * (i + 1) - (unsigned)s - 48, v == BZ_FOOTER_MAGIC, 9});
+            }
+        }
+    };
+    if (nthreads == 1) scan(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads; t++) th.emplace_back(scan, t);
+        for (auto &x : th) x.join();
+    }
     std::vector<BzCandidate> out;
     uint32_t level = 9, det;
     if (parse_bzip2_header(in, 0, in_len, &level, &det) != SEMZ_OK) level = 9;
-    // the first bytes of the two magics at each of the 8 bit alignments, to skip most positions quickly
-    uint64_t w = 0;                                       // the last 8 bytes, big-endian
-    for (uint64_t i = 0; i < in_len; i++) {
-        w = (w << 8) | in[i];
-        if (i < 5) continue;
-        // w holds bytes i-7..i; a 48-bit pattern that ends at bit s (0..7) before the end of byte i
-        for (unsigned s = 0; s < 8; s++) {
-            const uint64_t v = (w >> s) & 0xFFFFFFFFFFFFull;
-            if (v != BZ_BLOCK_MAGIC && v != BZ_FOOTER_MAGIC) continue;
-            if (i < 6 && s != 0) continue;                // needs 7 bytes unless byte aligned
-            const uint64_t bit = 8 * (i + 1) - s - 48;
-            BzCandidate c{bit, v == BZ_FOOTER_MAGIC, level};
+    for (auto &p : parts)
+        for (auto c : p) {
+            c.level = level;
             out.push_back(c);
             if (c.footer) {
                 // a following stream header, if any, sets the level of the next blocks
-                const uint64_t next = (bit + 48 + 32 + 7) >> 3;
+                const uint64_t next = (c.bit + 48 + 32 + 7) >> 3;
                 uint32_t lv;
                 if (next + 4 <= in_len && parse_bzip2_header(in, next, in_len, &lv, &det) == SEMZ_OK) level = lv;
             }
         }
-    }
-    // candidates found at the same byte come out with decreasing bit offset; put them in order
-    for (size_t a = 1; a < out.size(); a++)
-        for (size_t b = a; b > 0 && out[b].bit < out[b - 1].bit; b--) std::swap(out[b], out[b - 1]);
     return out;
 }
 
