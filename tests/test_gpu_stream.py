@@ -158,3 +158,37 @@ def test_lzma2_streams(engine):
         bad = bytearray(bytes([16]) + raw)
         bad[rng.randrange(1, len(bad))] ^= 1 << rng.randrange(8)
         compare(engine, 7, bytes(bad))
+
+
+def test_plain_gzip_members_with_lookalike_headers(engine):
+    """Concatenated members without an index are decoded as one speculative batch (every 1F 8B 08 is a candidate):
+    look-alike headers inside member data, members the hypothesis cannot size, damage and trailing data must
+    all come out as the sequential walk of the reference has them (interface.lisp:91-133)."""
+    rng = random.Random(40)
+    fake = b"\x1f\x8b\x08\x00" + bytes(14)
+    parts = []
+    for i in range(12):
+        body = corpus.mixed(rng.randrange(0, 40000), seed=50 + i)
+        if i % 3 == 0:
+            body = body[:100] + fake * 3 + body[100:] + fake          # ends up verbatim in stored blocks at level 0
+        parts.append(body)
+    members = [gzip.compress(p, 0 if i % 3 == 0 else 6) for i, p in enumerate(parts)]
+    data = b"".join(members)
+    got, res, info = compare(engine, 2, data)
+    assert got == b"".join(parts) and info.nmembers == 12 and res.status == 0
+    got, _, _ = compare(engine, 2, data, all_members=False)
+    assert got == parts[0]
+    compare(engine, 2, data + fake)                                   # a header and nothing else
+    compare(engine, 2, data + b"\x1f\x8b\x08")                        # truncated header
+    compare(engine, 2, data[:-9])                                     # last member without its trailer
+    for k in (1, 5, 11):                                              # damage inside member k
+        off = sum(len(m) for m in members[:k]) + len(members[k]) // 2
+        bad = bytearray(data)
+        bad[off] ^= 0x40
+        compare(engine, 2, bytes(bad))
+    wrong = bytearray(data)                                           # ISIZE of member 3 wrong: its span is mis-sized
+    off = sum(len(m) for m in members[:4]) - 4
+    wrong[off] ^= 0xFF
+    compare(engine, 2, bytes(wrong))
+    wrong[off + 3] ^= 0x7F                                            # and implausibly large
+    compare(engine, 2, bytes(wrong))
