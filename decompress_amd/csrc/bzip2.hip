@@ -36,7 +36,7 @@ constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:2
 constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
 constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
 // the walk keeps the first 4 S bytes of every chain (S = marker spacing) in a row of its own: (n / S + 2) rows
-constexpr size_t BZ_TEMP_STRIDE = 4 * (size_t)900032 + 16384;
+constexpr size_t BZ_TEMP_STRIDE = 4 * (size_t)900032 + 32768;   // + where each long chain goes on (4 B per chain)
 constexpr int BWT_THREADS = 512;               // bz_bwt_kernel: three workgroups fit a CU (49 KB of LDS each), so a
 constexpr int BWT_WAVES = BWT_THREADS / 64;    // 600-block batch is resident at once instead of in two rounds
 
@@ -848,6 +848,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     // lengths are spread geometrically around S, 2 % are longer), and once the chains are linked the rows are
     // copied to their places with coalesced accesses.  Only the chains longer than a row are walked a second time.
     const uint32_t CAP = 4 * S;
+    uint32_t *resume = reinterpret_cast<uint32_t *>(temp + (size_t)nmark * CAP);   // k after CAP steps, per chain
     if (n) {
         for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
             uint32_t k[4], len[4], acc[4];
@@ -876,6 +877,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
                     const uint32_t nk = v >> 8;
                     len[c]++;
                     k[c] = nk;
+                    if (len[c] == CAP) resume[id0 + c * BWT_THREADS] = nk;
                     if (nk == orig || (nk & (S - 1)) == 0) {
                         act[c] = false;
                         if (len[c] <= CAP && (len[c] & 3)) row[c][len[c] >> 2] = acc[c];
@@ -909,17 +911,29 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     const uint32_t cyc = misc[0];
     const uint32_t wlim = cyc < n ? cyc : n;
     if (n) {
-        // rows to their places, one chain per wave at a time
+        // rows to their places, one chain per wave at a time, four 64-byte pieces in flight
         for (uint32_t id = wave; id < nmark; id += BWT_WAVES) {
             const uint32_t so = seg_off[id];
             if (so == 0xFFFFFFFFu) continue;
             uint32_t ln = seg_len[id];
-            if (ln > CAP) continue;
+            if (ln > CAP) ln = CAP;
             if (so + ln > wlim) ln = so < wlim ? wlim - so : 0;
             const uint8_t *src = temp + (size_t)id * CAP;
-            for (uint32_t j = lane; j < ln; j += 64) post[so + j] = src[j];
+            for (uint32_t j0 = 0; j0 < ln; j0 += 256) {
+                uint8_t b[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t j = j0 + 64 * q + lane;
+                    b[q] = j < ln ? src[j] : (uint8_t)0;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t j = j0 + 64 * q + lane;
+                    if (j < ln) post[so + j] = b[q];
+                }
+            }
         }
-        // the long chains again, straight to their places
+        // the long chains go on from where their row ended, straight to their places
         for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
             uint32_t k[4], o[4], e[4];
             bool act[4];
@@ -928,9 +942,9 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
             for (int c = 0; c < 4; c++) {
                 uint32_t id = id0 + c * BWT_THREADS;
                 act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu && seg_len[id] > CAP;
-                k[c] = id == 0 ? orig : (id - 1) * S;
-                o[c] = act[c] ? seg_off[id] : 0;
-                e[c] = act[c] ? o[c] + seg_len[id] : 0;
+                k[c] = act[c] ? resume[id] : 0;
+                o[c] = act[c] ? seg_off[id] + CAP : 0;
+                e[c] = act[c] ? seg_off[id] + seg_len[id] : 0;
                 any = any || act[c];
             }
             while (any) {
