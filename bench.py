@@ -294,7 +294,7 @@ def main():
                          "other_kernels_ms_avg": {n: round(avg[n], 4) for n in names if n != kname},
                          "note": ISSUE_NOTES.get(a.format)},
         }
-        if a.format in ("gzip", "bzip2", "xz") and not a.no_e2e:
+        if a.format in ("gzip", "bzip2", "xz") and not a.no_e2e and world == 1:
             # the drop-in call on host buffers (pageable): split on the host, upload, kernels, download
             fmt_id = {"gzip": _lib.FMT_GZIP, "bzip2": _lib.FMT_BZIP2, "xz": _lib.FMT_XZ}[a.format]
             def c_call():                                   # the C ABI itself, as a Lisp host would call it through CFFI
@@ -311,7 +311,7 @@ def main():
             e2e = min(c_call(), c_call())
             line["end_to_end"] = {"value": round(total_out / e2e / 1e9, 3), "unit": "GB/s", "ms": round(e2e * 1e3, 2),
                                   "path": "one semz_decode_stream call on pageable host buffers: host split, H2D, kernels, D2H into a fresh buffer; never `value`"}
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.format, blobs, W["sample_out"])
         print(json.dumps(line), flush=True)
 

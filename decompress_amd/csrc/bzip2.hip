@@ -788,7 +788,19 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     __syncthreads();
     const uint32_t chunk = (((n + BWT_WAVES - 1) / BWT_WAVES) + 63) & ~63u;
     const uint32_t cbeg = wave * chunk, cend = cbeg + chunk < n ? cbeg + chunk : n;
-    for (uint32_t i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + pre[i]], 1u);
+    // (eight 64-byte pieces are loaded before any is used: one wave reading its chunk piece by piece is bound by
+    // the latency of each load otherwise)
+    for (uint32_t b0 = cbeg; b0 < cend; b0 += 512) {
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = b0 + 64 * q + lane;
+            v[q] = i < cend ? pre[i] : 0x100u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            if (v[q] < 0x100u) atomicAdd(&hist[wave * 256 + v[q]], 1u);
+    }
     __syncthreads();
     // ---- 2. prefix sums: cumm[v] (bzip2.lisp:150-151) and each wave's base per byte value ----
     if (tid < 256) {
@@ -805,26 +817,37 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     for (uint32_t i = tid; i < BWT_WAVES * 256; i += BWT_THREADS) hist[i] += cumm[i & 255];
     __syncthreads();
     // ---- 3. stable scatter: tt[cumm[v]++] = (i << 8) | v  (bzip2.lisp:153-156) ----
-    for (uint32_t b0 = cbeg; b0 < cend; b0 += 64) {
-        const uint32_t i = b0 + lane;
-        const bool valid = i < cend;
-        const uint32_t v = valid ? pre[i] : 0;
-        uint64_t same = __ballot(valid);
+    for (uint32_t b8 = cbeg; b8 < cend; b8 += 512) {
+        uint32_t vq[8];
 #pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
-            uint64_t bm = __ballot((v >> bit) & 1);
-            same &= ((v >> bit) & 1) ? bm : ~bm;
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = b8 + 64 * q + lane;
+            vq[q] = i < cend ? pre[i] : 0u;
         }
-        const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
-        const uint32_t cnt = __popcll(same);
-        uint32_t old = 0;
-        if (valid) old = hist[wave * 256 + v];
-        __builtin_amdgcn_wave_barrier();
-        if (valid) {
-            tt[old + rank] = (i << 8) | v;
-            if (rank == 0) hist[wave * 256 + v] = old + cnt;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t b0 = b8 + 64 * q;
+            if (b0 >= cend) break;
+            const uint32_t i = b0 + lane;
+            const bool valid = i < cend;
+            const uint32_t v = vq[q];
+            uint64_t same = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                uint64_t bm = __ballot((v >> bit) & 1);
+                same &= ((v >> bit) & 1) ? bm : ~bm;
+            }
+            const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
+            const uint32_t cnt = __popcll(same);
+            uint32_t old = 0;
+            if (valid) old = hist[wave * 256 + v];
+            __builtin_amdgcn_wave_barrier();
+            if (valid) {
+                tt[old + rank] = (i << 8) | v;
+                if (rank == 0) hist[wave * 256 + v] = old + cnt;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     __threadfence_block();
     __syncthreads();
