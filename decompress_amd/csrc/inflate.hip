@@ -168,6 +168,12 @@ __device__ __forceinline__ uint32_t canon_find(const TreeMeta &m, uint32_t v15, 
     return 0;
 }
 
+// Placed right behind a lane-masked store: the two paths of the mask then join here, in a block without phis.
+// Without it the optimiser lets each path jump on its own to the next merge of scalar state (a loop latch,
+// say), the uniformity analysis sees scalars merged behind a divergent branch, and the decoder state moves
+// from SGPRs to VGPRs.  Emits no instruction.
+__device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); }
+
 // Wave-parallel construction of one canonical tree (lengths->ht,
 // huffman.lisp:142-225): per-length counts (one lane per length), the
 // exact-completeness check (huffman.lisp:166-184), the sorted symbol list and
@@ -177,12 +183,24 @@ __device__ __forceinline__ void build_tree(const uint8_t *lens, int n, TreeMeta 
                                            MakeEntry make_entry)
 {
     const int lane = threadIdx.x & 63;
-    // 1. counts
-    uint32_t c = 0;
-    if (lane >= 1 && lane < 16)
-        for (int s = 0; s < n; s++) c += (lens[s] == lane);
-    if (lane < 16) m.count[lane] = (uint16_t)c;
+    // 1. counts, lanes = symbols: four ballots find the lanes of a piece that hold the same length, and the first
+    //    of each such set adds the set's size to the length's counter (one writer per counter: no atomics)
+    const uint64_t below = (1ull << lane) - 1;
+    if (lane < 16) m.count[lane] = 0;
     lds_sync();
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t len = s < n ? lens[s] : 0u;
+        uint64_t same = __builtin_amdgcn_ballot_w64(len != 0);
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const uint64_t bm = __builtin_amdgcn_ballot_w64((len >> bit) & 1);
+            same &= ((len >> bit) & 1) ? bm : ~bm;
+        }
+        if (len && (same & below) == 0) m.count[len] = (uint16_t)(m.count[len] + (uint32_t)__builtin_popcountll(same));
+        join_lanes();
+        lds_sync();
+    }
     // 2. canonical bookkeeping by one lane
     if (lane == 0) {
         uint32_t code = 0, off = 0, total = 0, minl = 20, maxl = 1;
@@ -204,13 +222,30 @@ __device__ __forceinline__ void build_tree(const uint8_t *lens, int n, TreeMeta 
     }
     lds_sync();
     if (uni(m.status) != SEMZ_OK) return;
-    // 3. sorted symbol list: lane L appends its symbols in ascending order
-    if (lane >= 1 && lane < 16) {
-        uint32_t k = m.offs[lane];
-        for (int s = 0; s < n; s++)
-            if (lens[s] == lane) sorted[k++] = (SortT)s;
-    }
+    // 3. sorted symbol list, again lanes = symbols: a symbol's place is its length's running offset plus its rank
+    //    among the lanes of the piece with the same length (m.count is the running offset from here on)
+    if (lane < 16) m.count[lane] = m.offs[lane];
     lds_sync();
+    for (int base = 0; base < n; base += 64) {
+        const int s = base + lane;
+        const uint32_t len = s < n ? lens[s] : 0u;
+        uint64_t same = __builtin_amdgcn_ballot_w64(len != 0);
+#pragma unroll
+        for (int bit = 0; bit < 4; bit++) {
+            const uint64_t bm = __builtin_amdgcn_ballot_w64((len >> bit) & 1);
+            same &= ((len >> bit) & 1) ? bm : ~bm;
+        }
+        const uint32_t rank = (uint32_t)__builtin_popcountll(same & below);
+        const uint32_t at = len ? m.count[len] : 0u;
+        join_lanes();
+        lds_sync();
+        if (len) {
+            sorted[at + rank] = (SortT)s;
+            if (rank == 0) m.count[len] = (uint16_t)(at + (uint32_t)__builtin_popcountll(same));
+        }
+        join_lanes();
+        lds_sync();
+    }
     // 4. root table, one index per lane per step (per-lane search: plain loads, no uni())
     for (int i = lane; i < (1 << ROOT_BITS); i += 64) {
         const uint32_t v15 = (__brev((uint32_t)i) >> (32 - ROOT_BITS)) << (15 - ROOT_BITS);
@@ -292,11 +327,6 @@ __device__ __forceinline__ uint32_t ld_bytes_le(const uint8_t *p, int n)
 }
 
 
-// Placed right behind a lane-masked store: the two paths of the mask then join here, in a block without phis.
-// Without it the optimiser lets each path jump on its own to the next merge of scalar state (a loop latch,
-// say), the uniformity analysis sees scalars merged behind a divergent branch, and the decoder state moves
-// from SGPRs to VGPRs.  Emits no instruction.
-__device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); }
 
 // wave-wide inclusive prefix maximum of unsigned values (identity 0)
 __device__ __forceinline__ uint32_t wave_scan_max(uint32_t v)
