@@ -892,25 +892,32 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                     const int total = nlit + ndist;
                     int i = 0;
                     uint32_t prev = 0;
+                    uint32_t x = 0, have = 0;                // the next `have` bits of the input from P on
                     while (i < total) {
-                        ensure_staged();
-                        const uint32_t x = rd32(P);
+                        if (have < 14) {                     // a code takes at most 7 bits and 7 extra bits
+                            ensure_staged();
+                            x = rd32(P);
+                            have = 32;
+                        }
                         const uint32_t ce = uni((uint32_t)L.clen_root[x & ((1u << CLEN_ROOT_BITS) - 1)]);
                         const uint32_t cl = ce & 7;
                         if (short_of(cfull ? cmaxl : cl)) { st.set(SEMZ_EOF, 0); break; }
                         P += cl;
+                        x >>= cl;
+                        have -= cl;
                         const uint32_t sym = ce >> 3;
                         if (sym < 16) {
-                            if (lane == 0) L.lens[i] = (uint8_t)sym;
-                            join_lanes();
+                            L.lens[i] = (uint8_t)sym;        // every lane, same address, same value
                             prev = sym;
                             i++;
                             continue;
                         }
                         const uint32_t xb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
                         if (short_of(xb)) { st.set(SEMZ_EOF, 0); break; }
-                        const int n = (sym == 18 ? 11 : 3) + (int)((x >> cl) & ((1u << xb) - 1));
+                        const int n = (sym == 18 ? 11 : 3) + (int)(x & ((1u << xb) - 1));
                         P += xb;
+                        x >>= xb;
+                        have -= xb;
                         if (i + n > total) { st.set(SEMZ_E_DEFLATE_CODELEN_BOUNDS, 0); break; }
                         uint32_t v = 0;
                         if (sym == 16) {
@@ -919,6 +926,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
                         }
                         for (int k0 = 0; k0 < n; k0 = uni(k0 + 64))
                             if (k0 + (int)lane < n) L.lens[i + k0 + lane] = (uint8_t)v;
+                        join_lanes();
                         prev = v;
                         i += n;
                     }
