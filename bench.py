@@ -27,10 +27,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # what the SQ counters (profiles/r01_*_pmc_sq.txt) say bounds the dominant kernel in practice
 ISSUE_NOTES = {
-    "gzip": "instruction-issue bound: scalar pipe 71 %, vector pipe 62 % of their issue rate (profiles/r01_gzip_pmc_sq.txt)",
+    "gzip": "instruction-issue bound: scalar pipe 70 %, vector pipe 62 % of their issue rate (profiles/r01_gzip_pmc_sq.txt)",
     "zlib": "instruction-issue bound like gzip, plus per-record table builds",
-    "bzip2": "bz_bwt_kernel: one random HBM line per output byte, 87 % of wave cycles waiting on memory; bz_decode_kernel: latency of two serial waves per block",
-    "xz": "serial range decoder: 25 instructions and one LDS round trip per bit, two waves per SIMD",
+    "bzip2": "bz_decode_kernel: latency of two serial waves per block; bz_bwt_kernel: one random HBM line per output byte, 81 % of wave cycles waiting on memory",
+    "xz": "serial range decoder: about 50 instructions and one LDS round trip per decoded bit, two waves per SIMD",
 }
 METRIC = "decompressed GB/s (node) batched gzip/bzip2 blocks @1/2/4/8 GPUs; % HBM peak"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

@@ -11,14 +11,14 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for F in gzip zlib bzip2 xz; do
     timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${F}_kt -- \
-        python3 $R/bench.py --format $F --steps 5 --warmup 2 --no-cpu --workers 1 > $O/${F}_kt.log 2>&1
+        python3 $R/bench.py --format $F --steps 5 --warmup 2 --no-cpu --no-e2e --workers 1 > $O/${F}_kt.log 2>&1
     find $O -name "${F}_kt_kernel_stats.csv" -exec cp {} $O/ \; 2>/dev/null || true
     echo "$F done"
 done
 for C in FETCH_SIZE WRITE_SIZE; do
     N=$(echo $C | tr A-Z a-z | cut -d_ -f1)
     timeout -s KILL 170 rocprofv3 --pmc $C --output-format csv -d $O -o gzip_$N -- \
-        python3 $R/bench.py --format gzip --steps 2 --warmup 1 --no-cpu --workers 1 > $O/gzip_$N.log 2>&1
+        python3 $R/bench.py --format gzip --steps 2 --warmup 1 --no-cpu --no-e2e --workers 1 > $O/gzip_$N.log 2>&1
     find $O -name "gzip_${N}_counter_collection.csv" -exec cp {} $O/ \; 2>/dev/null || true
     echo "$C done"
 done
