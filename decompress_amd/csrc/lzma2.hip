@@ -151,28 +151,46 @@ struct Lz {
         // selects instead of branches, and the update stored by every lane (same address, same value: one LDS
         // pass) instead of by lane 0 behind an exec mask: both halve the instructions of the step
         const uint32_t p = uni((uint32_t)probs[idx]);
-        const uint32_t bound = p * (range >> 11);
-        const uint32_t r1 = range - bound, c1 = code - bound;
-        const uint32_t p1 = p - (p >> 5), p0 = p + ((2048 - p) >> 5);
-        const bool one = code >= bound;
-        range = one ? r1 : bound;
-        code = one ? c1 : code;
-        probs[idx] = (uint16_t)(one ? p1 : p0);
+        uint32_t np, one;
+        step(p, np, one);
+        probs[idx] = (uint16_t)np;
         normalize();
-        return one ? 1u : 0u;
+        return one;
+    }
+    // The arithmetic of one bit, fourteen scalar instructions.  Written out: given the C form the compiler keeps
+    // the comparison as a lane mask and takes the bit's value through a VGPR and back (five more instructions).
+    __device__ __forceinline__ void step(uint32_t p, uint32_t &np, uint32_t &one)
+    {
+        uint32_t bound, t0, t1, t2, t3;
+        asm("s_lshr_b32 %[bound], %[range], 11\n\t"
+            "s_mul_i32 %[bound], %[bound], %[p]\n\t"
+            "s_lshr_b32 %[t0], %[p], 5\n\t"
+            "s_sub_u32 %[t0], %[p], %[t0]\n\t"              // p - (p >> 5)
+            "s_sub_u32 %[t1], 0x800, %[p]\n\t"
+            "s_lshr_b32 %[t1], %[t1], 5\n\t"
+            "s_add_u32 %[t1], %[p], %[t1]\n\t"              // p + ((2048 - p) >> 5)
+            "s_sub_u32 %[t2], %[range], %[bound]\n\t"
+            "s_sub_u32 %[t3], %[code], %[bound]\n\t"
+            "s_cmp_ge_u32 %[code], %[bound]\n\t"
+            "s_cselect_b32 %[range], %[t2], %[bound]\n\t"
+            "s_cselect_b32 %[code], %[t3], %[code]\n\t"
+            "s_cselect_b32 %[np], %[t0], %[t1]\n\t"
+            "s_cselect_b32 %[one], 1, 0"
+            : [range] "+s"(range), [code] "+s"(code), [np] "=&s"(np), [one] "=&s"(one), [bound] "=&s"(bound),
+              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
+            : [p] "s"(p)
+            : "scc");
     }
     // same over probabilities kept in HBM (the literal coder of SEMZ_UNIT_LZMA_WIDE); L2-coherent accesses, so
     // that the wave reads back its own updates
     __device__ __forceinline__ uint32_t bit_g(uint16_t *probs, uint32_t idx)
     {
         const uint32_t p = uni((uint32_t)__hip_atomic_load(probs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const uint32_t bound = p * (range >> 11);
-        uint32_t b, np;
-        if (code >= bound) { range -= bound; code -= bound; np = p - (p >> 5); b = 1; }
-        else { range = bound; np = p + ((2048 - p) >> 5); b = 0; }
+        uint32_t np, one;
+        step(p, np, one);
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(probs + idx, (uint16_t)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         normalize();
-        return b;
+        return one;
     }
     __device__ __forceinline__ uint32_t be_bits(uint16_t *probs, uint32_t base, uint32_t count)   // lzma.lisp:122-135
     {
