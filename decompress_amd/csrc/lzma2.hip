@@ -150,36 +150,50 @@ struct Lz {
     {
         // selects instead of branches, and the update stored by every lane (same address, same value: one LDS
         // pass) instead of by lane 0 behind an exec mask: both halve the instructions of the step
-        const uint32_t p = uni((uint32_t)probs[idx]);
+        const uint32_t raw = probs[idx];                 // ds_read_u16 zero-extends
         uint32_t np, one;
-        step(p, np, one);
+        step<true>(raw, np, one);
         probs[idx] = (uint16_t)np;
         normalize();
         return one;
     }
     // The arithmetic of one bit, fourteen scalar instructions.  Written out: given the C form the compiler keeps
     // the comparison as a lane mask and takes the bit's value through a VGPR and back (five more instructions).
-    __device__ __forceinline__ void step(uint32_t p, uint32_t &np, uint32_t &one)
+    // FROM_LANES: `pin` is the probability as the lanes loaded it (the same in every lane); it comes over with
+    // v_readfirstlane inside the sequence, where the compiler would add a mask and a wait state around it.
+    template <bool FROM_LANES> __device__ __forceinline__ void step(uint32_t pin, uint32_t &np, uint32_t &one)
     {
-        uint32_t bound, t0, t1, t2, t3;
-        asm("s_lshr_b32 %[bound], %[range], 11\n\t"
-            "s_mul_i32 %[bound], %[bound], %[p]\n\t"
-            "s_lshr_b32 %[t0], %[p], 5\n\t"
-            "s_sub_u32 %[t0], %[p], %[t0]\n\t"              // p - (p >> 5)
-            "s_sub_u32 %[t1], 0x800, %[p]\n\t"
-            "s_lshr_b32 %[t1], %[t1], 5\n\t"
-            "s_add_u32 %[t1], %[p], %[t1]\n\t"              // p + ((2048 - p) >> 5)
-            "s_sub_u32 %[t2], %[range], %[bound]\n\t"
-            "s_sub_u32 %[t3], %[code], %[bound]\n\t"
-            "s_cmp_ge_u32 %[code], %[bound]\n\t"
-            "s_cselect_b32 %[range], %[t2], %[bound]\n\t"
-            "s_cselect_b32 %[code], %[t3], %[code]\n\t"
-            "s_cselect_b32 %[np], %[t0], %[t1]\n\t"
+        uint32_t bound, t0, t1, t2, t3, p;
+#define LZ_STEP_BODY                                                                                         \
+            "s_lshr_b32 %[bound], %[range], 11\n\t"                                                           \
+            "s_mul_i32 %[bound], %[bound], %[p]\n\t"                                                          \
+            "s_lshr_b32 %[t0], %[p], 5\n\t"                                                                   \
+            "s_sub_u32 %[t0], %[p], %[t0]\n\t"              /* p - (p >> 5) */                                \
+            "s_sub_u32 %[t1], 0x800, %[p]\n\t"                                                                \
+            "s_lshr_b32 %[t1], %[t1], 5\n\t"                                                                  \
+            "s_add_u32 %[t1], %[p], %[t1]\n\t"              /* p + ((2048 - p) >> 5) */                       \
+            "s_sub_u32 %[t2], %[range], %[bound]\n\t"                                                         \
+            "s_sub_u32 %[t3], %[code], %[bound]\n\t"                                                          \
+            "s_cmp_ge_u32 %[code], %[bound]\n\t"                                                              \
+            "s_cselect_b32 %[range], %[t2], %[bound]\n\t"                                                     \
+            "s_cselect_b32 %[code], %[t3], %[code]\n\t"                                                       \
+            "s_cselect_b32 %[np], %[t0], %[t1]\n\t"                                                           \
             "s_cselect_b32 %[one], 1, 0"
-            : [range] "+s"(range), [code] "+s"(code), [np] "=&s"(np), [one] "=&s"(one), [bound] "=&s"(bound),
-              [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
-            : [p] "s"(p)
-            : "scc");
+        if constexpr (FROM_LANES) {
+            asm("v_readfirstlane_b32 %[p], %[pv]\n\t" LZ_STEP_BODY
+                : [range] "+s"(range), [code] "+s"(code), [np] "=&s"(np), [one] "=&s"(one), [bound] "=&s"(bound),
+                  [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [p] "=&s"(p)
+                : [pv] "v"(pin)
+                : "scc");
+        } else {
+            p = pin;
+            asm(LZ_STEP_BODY
+                : [range] "+s"(range), [code] "+s"(code), [np] "=&s"(np), [one] "=&s"(one), [bound] "=&s"(bound),
+                  [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3)
+                : [p] "s"(p)
+                : "scc");
+        }
+#undef LZ_STEP_BODY
     }
     // same over probabilities kept in HBM (the literal coder of SEMZ_UNIT_LZMA_WIDE); L2-coherent accesses, so
     // that the wave reads back its own updates
@@ -187,7 +201,7 @@ struct Lz {
     {
         const uint32_t p = uni((uint32_t)__hip_atomic_load(probs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         uint32_t np, one;
-        step(p, np, one);
+        step<false>(p, np, one);
         if ((threadIdx.x & 63) == 0) __hip_atomic_store(probs + idx, (uint16_t)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         normalize();
         return one;
