@@ -30,7 +30,7 @@ ISSUE_NOTES = {
     "gzip": "instruction-issue bound: scalar pipe 70 %, vector pipe 62 % of their issue rate (profiles/r01_gzip_pmc_sq.txt)",
     "zlib": "instruction-issue bound like gzip, plus per-record table builds",
     "bzip2": "bz_decode_kernel: latency of two serial waves per block; bz_bwt_kernel: one random HBM line per output byte, 81 % of wave cycles waiting on memory",
-    "xz": "serial range decoder: about 50 instructions and one LDS round trip per decoded bit, two waves per SIMD",
+    "xz": "serial range decoder: about 47 instructions and one LDS round trip per decoded bit, two waves per SIMD",
 }
 METRIC = "decompressed GB/s (node) batched gzip/bzip2 blocks @1/2/4/8 GPUs; % HBM peak"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

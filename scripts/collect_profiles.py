@@ -24,7 +24,7 @@ for fmt in ("gzip", "bzip2", "xz", "zlib"):
     d = json.loads(line)
     with open(os.path.join(prof, f"{tag}_{fmt}_kernel_stats.txt"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --format {fmt} "
-                f"--steps {d["steps"]} --warmup {d["warmup"]} --no-cpu --no-e2e --workers 1   (MI355X)\n")
+                f"--steps {d['steps']} --warmup {d['warmup']} --no-cpu --no-e2e --workers 1   (MI355X)\n")
         f.write(f"# workload: {d['config']['workload']}\n")
         f.write(f"{'kernel':34s} {'calls':>6s} {'total_ms':>10s} {'avg_ms':>9s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>6s}\n")
         for r in rows:
