@@ -90,3 +90,35 @@ def test_xz_index_walk():
     bad = bytearray(data); bad[-1] ^= 1
     units, _ = split(_lib.FMT_XZ, bytes(bad))
     assert units == []
+
+
+def test_bzip2_magic_scan_large_input_in_slices():
+    """Inputs of 8 MiB and more are scanned in slices by several host threads: magics at every bit offset, also
+    across the slice borders, come out in order and none twice."""
+    import random
+    rng = random.Random(7)
+    n = 9 << 20
+    buf = bytearray(rng.getrandbits(8) for _ in range(1 << 16)) * (n >> 16)
+    head = b"BZh9"
+    buf[:4] = head
+    magic = 0x314159265359
+    want = []
+    borders = [n * t // 8 for t in range(1, 8)]
+    # one magic per slice border, each straddling it differently (they must not overlap each other)
+    places = [32 + 3, 1000 * 8 + 5] + [8 * b - 48 + d for b, d in zip(borders, (-9, 0, 1, 7, 23, 47, -47))] + [8 * n - 48]
+    for bit in sorted(set(places)):
+        # write the 48-bit pattern at an arbitrary bit offset, MSB first
+        for k in range(48):
+            pos = bit + k
+            byte, sh = pos >> 3, 7 - (pos & 7)
+            b = (magic >> (47 - k)) & 1
+            buf[byte] = (buf[byte] & ~(1 << sh)) | (b << sh)
+        want.append(bit)
+    units, info = split(_lib.FMT_BZIP2, bytes(buf))
+    got = [8 * u.in_off + u.in_bit_off for u in units]
+    assert got == sorted(got) and len(set(got)) == len(got)
+    assert set(want) <= set(got), sorted(set(want) - set(got))
+    # anything else the scan reports must really be a magic (random data: practically none)
+    for bit in set(got) - set(want):
+        v = int.from_bytes(bytes(buf[bit >> 3:(bit >> 3) + 7]), "big") >> (8 - (bit & 7)) & ((1 << 48) - 1)
+        assert v == magic
