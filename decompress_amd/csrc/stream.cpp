@@ -210,7 +210,9 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                     total += (isize + 15) & ~15ull;
                     units.push_back(u);
                 }
-                if (units.size() >= 2) {
+                // (look-alike headers in a large single member can hypothesise gigabytes each: speculation is only
+                // worth a bounded amount of memory, otherwise the members are decoded one after the other)
+                if (units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len)) {
                     int rc = R.reserve(total);
                     if (rc) return rc;
                     std::vector<semz_result> res;
