@@ -108,15 +108,14 @@ std::vector<BzCandidate> scan_bzip2(const uint8_t *in, uint64_t in_len)
 {
     // A 64 Ki-entry filter on the last two bytes of the window rejects 99 % of the positions before the eight
     // shifted 48-bit compares; the input is scanned in slices by a few host threads.
-    static uint8_t maybe[65536];
-    static bool ready = false;
-    if (!ready) {
+    static const std::vector<uint8_t> maybe = [] {          // initialised once, thread-safe (C++11 static)
+        std::vector<uint8_t> m(65536, 0);
         for (unsigned s = 0; s < 8; s++)
             for (uint64_t magic : {BZ_BLOCK_MAGIC, BZ_FOOTER_MAGIC})
                 for (unsigned low = 0; low < (1u << s); low++)
-                    maybe[(uint16_t)((magic << s) | low)] = 1;
-        ready = true;
-    }
+                    m[(uint16_t)((magic << s) | low)] = 1;
+        return m;
+    }();
     const unsigned nthreads = in_len >= (8u << 20) ? 8 : 1;
     std::vector<std::vector<BzCandidate>> parts(nthreads);
     auto scan = [&](unsigned t) {
