@@ -504,11 +504,11 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
                 }
                 while (symbol < 0x100) symbol = (symbol << 1) | lit_bit(base + symbol);
                 if (p == cap_end) { z.fail(SEMZ_E_OUT_CAP, 0); break; }
-                if (lane == 0) L.ring[(uint32_t)(p + shift) & LZ_MASK] = (uint8_t)symbol;
+                L.ring[(uint32_t)(p + shift) & LZ_MASK] = (uint8_t)symbol;      // every lane: same address, same value
                 p++;
                 total_i++;
                 history = history < 4 ? 0 : history < 10 ? history - 3 : history - 6;   // lzma.lisp:615
-                if (p - flushed >= (uint64_t)LZ_FLUSH + 16) { lds_sync(); flush(false); }
+                if ((uint32_t)p - (uint32_t)flushed >= (uint32_t)LZ_FLUSH + 16) { lds_sync(); flush(false); }   // (the difference is below the ring size)
                 continue;
             }
             if (z.bit(L.probs, P_IS_SIMPLE + history) == 0) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
             }
             p += len;
             total_i += len;
-            if (p - flushed >= (uint64_t)LZ_FLUSH + 16) flush(false);
+            if ((uint32_t)p - (uint32_t)flushed >= (uint32_t)LZ_FLUSH + 16) flush(false);
         }
         total_i &= 15;
         if (z.status != SEMZ_OK) break;
