@@ -286,8 +286,8 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
     return SEMZ_OK;
 }
 
-__global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                        bz_meta *meta, uint8_t *pre_all)
+__global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units, uint32_t nunits,
+                                                        uint64_t out_total, bz_meta *meta, uint8_t *pre_all)
 {
     // Two waves per block, a producer and a consumer, joined by a symbol queue in LDS.  A lone wave issues one
     // instruction every ~5 clocks whatever its kind and a bzip2 batch has fewer blocks than the chip has SIMDs,
@@ -319,6 +319,14 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, const
     if (threadIdx.x < sizeof(BzShare) / 4) reinterpret_cast<uint32_t *>(&L.sh)[threadIdx.x] = 0;
     __syncthreads();
     const semz_unit un = units[u];
+    if (!semz_unit_spans_ok(un, in_len, out_total, 1)) {         // nothing of this unit is touched
+        if (threadIdx.x == 0) {
+            bz_meta m{};
+            m.status = SEMZ_E_BAD_UNIT;
+            meta[u] = m;
+        }
+        return;
+    }
     uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
     const uint32_t level = un.param0 >= 1 && un.param0 <= 9 ? un.param0 : 9;
     const uint32_t block_size = level * 100000u;
@@ -1194,7 +1202,6 @@ extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
 {
-    (void)in_len;
     void *meta, *pre, *post, *tt, *segs;
     int rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_META, (size_t)nunits * sizeof(bz_meta), &meta))) return rc;
@@ -1203,14 +1210,13 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * BZ_SEGS * sizeof(bz_seg), &segs))) return rc;
     post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
     const size_t smem = (3 * (BZ_CHAINS + 1) + 16) * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!c->bz_attr_set) {                      // per context, i.e. per device
         if (hipFuncSetAttribute((const void *)bz_bwt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return semz_fail(c, -2, "cannot reserve %zu bytes of LDS for bz_bwt_kernel", smem);
-        attr_set = true;
+        c->bz_attr_set = true;
     }
     semz_span_begin(c, "bz_decode_kernel");
-    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, d_units, nunits, (bz_meta *)meta, (uint8_t *)pre);
+    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre);
     semz_span_end(c);
     semz_span_begin(c, "bz_bwt_kernel");
     bz_bwt_kernel<<<nunits, BWT_THREADS, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,

@@ -353,8 +353,8 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v)
     return v;
 }
 
-__global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const semz_unit *units,
-                                                        uint32_t nunits, uint8_t *out,
+__global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units,
+                                                        uint32_t nunits, uint8_t *out, uint64_t out_total,
                                                         semz_result *results, semz_tail *tails)
 {
     __shared__ UnitLds L;
@@ -368,6 +368,16 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, const
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(semz_unit) / 4); i++) w[i] = up[i];
         __builtin_memcpy(&un, w, sizeof un);
+    }
+    if (!semz_unit_spans_ok(un, in_len, out_total, 0)) {         // nothing of this unit is touched
+        if (lane == 0) {
+            semz_result r{};
+            r.status = SEMZ_E_BAD_UNIT;
+            r.out_off = un.out_off;
+            results[u] = r;
+            tails[u] = semz_tail{};
+        }
+        return;
     }
 
     uint8_t *ob = out + un.out_off;
@@ -1040,10 +1050,10 @@ extern "C" int semz_debug_stamps(unsigned long long *out16, int reset)
 }
 #endif
 
-extern "C" void semz_launch_inflate(const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
-                                    uint8_t *d_out, semz_result *d_results, semz_tail *d_tails,
+extern "C" void semz_launch_inflate(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails,
                                     hipStream_t stream)
 {
     if (nunits == 0) return;
-    inflate_kernel<<<nunits, 64, 0, stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails);
+    inflate_kernel<<<nunits, 64, 0, stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails);
 }

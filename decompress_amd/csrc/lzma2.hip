@@ -263,9 +263,9 @@ constexpr uint32_t WIDE_LIT_PROBS = 0x300u << 12;               // lc <= 8, lp <
 // WIDE: the literal coder's probabilities live in `wide` (WIDE_LIT_PROBS entries per unit) instead of LDS
 // SMALL: see LzSize; retry_pass: only the units that the small kernel left with LZ_RETRY_FULL are decoded
 template <bool WIDE, bool SMALL>
-__global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const semz_unit *units, uint32_t nunits,
-                                                      uint8_t *out, semz_result *results, semz_tail *tails, uint16_t *wide,
-                                                      int retry_pass)
+__global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units, uint32_t nunits,
+                                                      uint8_t *out, uint64_t out_total, semz_result *results, semz_tail *tails,
+                                                      uint16_t *wide, int retry_pass)
 {
     constexpr int LZ_RING = LzSize<SMALL>::RING, LZ_MASK = LzSize<SMALL>::MASK, P_TOTAL = LzSize<SMALL>::TOTAL;
     constexpr uint32_t MAX_LCLP = LzSize<SMALL>::LCLP;
@@ -281,6 +281,16 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, const s
 #pragma unroll
         for (int i = 0; i < (int)(sizeof(semz_unit) / 4); i++) w[i] = up[i];
         __builtin_memcpy(&un, w, sizeof un);
+    }
+    if (!semz_unit_spans_ok(un, in_len, out_total, 2)) {         // nothing of this unit is touched
+        if (lane == 0) {
+            semz_result r{};
+            r.status = SEMZ_E_BAD_UNIT;
+            r.out_off = un.out_off;
+            results[u] = r;
+            tails[u] = semz_tail{};
+        }
+        return;
     }
     uint8_t *ob = out + un.out_off;
     const uint32_t shift = (uint32_t)((uintptr_t)ob & 15);
@@ -850,17 +860,16 @@ __global__ __launch_bounds__(256) void bcj_simple_kernel(const semz_unit *units,
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide)
 {
-    (void)in_len; (void)out_cap;
     semz_span_begin(c, "lzma2_kernel");
     if (wide) {
         void *w = nullptr;
         int rc = semz_scratch(c, SEMZ_SLOT_LZ_WIDE, (size_t)nunits * WIDE_LIT_PROBS * sizeof(uint16_t), &w);
         if (rc) return rc;
-        lzma2_kernel<true, false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, (uint16_t *)w, 0);
+        lzma2_kernel<true, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, (uint16_t *)w, 0);
     } else {
         // eight units per CU; the few units that need the full literal table are redone by the second launch
-        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr, 0);
-        lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, d_units, nunits, d_out, d_results, d_tails, nullptr, 1);
+        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 0);
+        lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 1);
     }
     semz_span_end(c);
     // filter chain stages (at most three non-last filters, xz.lisp:262); a kernel returns at once for

@@ -141,7 +141,6 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
     if (nunits == 0) return 0;
     if (!d_in || !d_units || !d_out || !d_results) return semz_fail(c, -1, "null device pointer");
     if (nunits > 0xFFFFFFF0u) return semz_fail(c, -1, "too many units");
-    (void)in_len; (void)out_cap;
     HIPCHK(c, hipSetDevice(c->device));
     void *tails = nullptr;
     int rc = semz_scratch(c, SEMZ_SLOT_TAILS, nunits * sizeof(semz_tail), &tails);
@@ -151,7 +150,7 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
     case SEMZ_UNIT_ZLIB:
     case SEMZ_UNIT_GZIP:
         semz_span_begin(c, "inflate_kernel");
-        semz_launch_inflate((const uint8_t *)d_in, d_units, (uint32_t)nunits, (uint8_t *)d_out,
+        semz_launch_inflate((const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,
                             d_results, (semz_tail *)tails, c->stream);
         semz_span_end(c);
         semz_span_begin(c, "checksum_kernel");

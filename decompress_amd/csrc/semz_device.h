@@ -27,6 +27,20 @@ struct semz_tail {
 enum { SEMZ_TK_NONE = 0, SEMZ_TK_CRC32 = 1, SEMZ_TK_ADLER32 = 2, SEMZ_TK_BZCRC = 3,
        SEMZ_TK_CRC64 = 4, SEMZ_TK_SHA256 = 5 };
 
+// Span checks of the device entry points (semz_decode_batch validates on the host and fails the call; the device
+// entry points cannot see the unit table, so every decode kernel starts with this and reports SEMZ_E_BAD_UNIT
+// for a unit whose spans leave the buffers of the call, without reading or writing anything through them).
+// family: 0 deflate/zlib/gzip, 1 bzip2 blocks, 2 xz blocks / LZMA2 / LZMA.
+__device__ __forceinline__ bool semz_unit_spans_ok(const semz_unit &un, uint64_t in_len, uint64_t out_cap, int family)
+{
+    const int fam = un.kind <= SEMZ_UNIT_GZIP ? 0 : un.kind == SEMZ_UNIT_BZIP2_BLOCK ? 1 : un.kind <= SEMZ_UNIT_LZMA_WIDE ? 2 : 3;
+    bool ok = fam == family && un.in_off <= un.in_limit && un.in_limit <= in_len && un.in_bit_off <= 7;
+    if (un.out_off == SEMZ_OUT_AUTO) ok = ok && family == 1;
+    else ok = ok && un.out_off <= out_cap && un.out_cap <= out_cap - un.out_off;
+    if (un.prefix_len) ok = ok && un.prefix_off <= in_len && un.prefix_len <= in_len - un.prefix_off;
+    return ok;
+}
+
 __device__ __forceinline__ void lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

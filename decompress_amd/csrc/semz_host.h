@@ -19,6 +19,7 @@ struct semz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     semz_check_tables *d_tabs = nullptr;
+    bool bz_attr_set = false;           // bz_bwt_kernel's LDS size has been raised on this device
     std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
     // optional per-kernel timing (semz_set_option "profile"): event pairs on `stream`
     bool profile = false;
@@ -49,8 +50,8 @@ int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p);
 
 extern "C" {
 void semz_build_check_tables(semz_check_tables *t);
-void semz_launch_inflate(const uint8_t *d_in, const semz_unit *d_units, uint32_t nunits,
-                         uint8_t *d_out, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
+void semz_launch_inflate(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
+                         uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
 void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32_t nunits,
                           semz_result *d_results, const semz_tail *d_tails,
                           const semz_check_tables *d_tabs, uint32_t kind_mask, hipStream_t stream);

@@ -1,5 +1,6 @@
 // split.cpp -- host splitter: finds the independent units of a multi-unit input
 // without decoding it (include/semz_gpu.h semz_split).
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -10,16 +11,15 @@ namespace semz {
 
 uint32_t crc32_host(const uint8_t *p, size_t n)          // crc.lisp:19-110
 {
-    static uint32_t table[256];
-    static bool ready = false;
-    if (!ready) {
+    static const std::array<uint32_t, 256> table = [] {     // initialised once, thread-safe (C++11 static)
+        std::array<uint32_t, 256> t{};
         for (uint32_t i = 0; i < 256; i++) {
             uint32_t c = i;
             for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
-            table[i] = c;
+            t[i] = c;
         }
-        ready = true;
-    }
+        return t;
+    }();
     uint32_t c = 0xFFFFFFFFu;
     for (size_t i = 0; i < n; i++) c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
     return ~c;

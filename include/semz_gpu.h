@@ -145,7 +145,14 @@ int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
 /* Same, everything device-resident (d_* are device pointers of this ctx's GPU);
  * asynchronous on the context's stream until semz_sync().  `kind` names the
  * family of the batch (any SEMZ_UNIT_* value of that family).  This is the
- * call the benchmark times. */
+ * call the benchmark times.
+ * The unit table lives on the device, so the host cannot check it: every decode
+ * kernel checks its unit's spans against in_len / out_cap first and reports
+ * SEMZ_E_BAD_UNIT in that unit's result, without touching memory through the
+ * unit, when in_off > in_limit, in_limit > in_len, out_off + out_cap > out_cap
+ * (of the call), the prefix span leaves `in`, in_bit_off > 7 or the kind is not
+ * of the batch's family.  d_in needs no padding: the kernels read whole aligned
+ * 16-byte words around the spans, which never leave the pages the spans lie on. */
 int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
                              const semz_unit *d_units, size_t nunits,
                              void *d_out, size_t out_cap, semz_result *d_results);
