@@ -54,7 +54,7 @@ _lib = None
 
 EXPORTS = [
     "semz_open", "semz_close", "semz_last_error", "semz_strerror", "semz_decode_batch",
-    "semz_decode_batch_device", "semz_set_option", "semz_sync", "semz_stream",
+    "semz_decode_batch_device", "semz_decode_batch_device_noalloc", "semz_set_option", "semz_sync", "semz_stream",
     "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
     "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
     "semz_split", "semz_free", "semz_decode_stream",
@@ -83,6 +83,7 @@ def load():
     lib.semz_decode_batch.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(Unit), C.c_size_t,
                                       vp, C.c_size_t, C.POINTER(Result)]
     lib.semz_decode_batch_device.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp]
+    lib.semz_decode_batch_device_noalloc.argtypes = lib.semz_decode_batch_device.argtypes
     lib.semz_set_option.argtypes = [vp, C.c_char_p, C.c_long]
     lib.semz_sync.argtypes = [vp]
     lib.semz_stream.argtypes = [vp]
@@ -176,6 +177,10 @@ class Engine:
     def decode_batch_device(self, kind, d_in, in_len, d_units, nunits, d_out, out_cap, d_results):
         self._chk(self.lib.semz_decode_batch_device(self.h, kind, d_in, in_len, d_units, nunits,
                                                     d_out, out_cap, d_results))
+
+    def decode_batch_device_noalloc(self, kind, d_in, in_len, d_units, nunits, d_out, out_cap, d_results):
+        self._chk(self.lib.semz_decode_batch_device_noalloc(self.h, kind, d_in, in_len, d_units, nunits,
+                                                            d_out, out_cap, d_results))
 
     def sync(self):
         self._chk(self.lib.semz_sync(self.h))

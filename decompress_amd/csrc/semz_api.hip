@@ -60,6 +60,14 @@ extern "C" void semz_profile_reset(semz_ctx *c)
     c->spans.clear();
 }
 
+// ---- scratch of the entry point that allocates nothing (semz_decode_batch_device_noalloc) ----
+// The deflate-family kernels hand the trailer fields of every unit to the checksum kernel through a table of
+// semz_tail records (64 bytes per unit), which semz_decode_batch_device keeps in grow-only hipMalloc'ed scratch.
+// Callers that cannot allocate get it from this static array instead: 4 MiB per GPU the library runs on, held
+// until the process ends.  In host code `scratch` is only a stand-in for the symbol; the array's address on a
+// device comes from hipGetSymbolAddress (semz_open, with that device current) and lives in the context.
+static __device__ __align__(256) unsigned char scratch[SEMZ_NOALLOC_MAX_UNITS * sizeof(semz_tail)];
+
 extern "C" int semz_open(int device, semz_ctx **out)
 {
     if (!out) return -1;
@@ -75,7 +83,13 @@ extern "C" int semz_open(int device, semz_ctx **out)
     hipError_t e = hipMalloc((void **)&c->d_tabs, sizeof(semz_check_tables));
     if (e == hipSuccess) e = hipMemcpy(c->d_tabs, h, sizeof(semz_check_tables), hipMemcpyHostToDevice);
     delete h;
-    if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return -2; }
+    if (e == hipSuccess) e = hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch));   // this device's copy
+    if (e != hipSuccess || !c->noalloc_scratch) {
+        if (c->d_tabs) hipFree(c->d_tabs);
+        hipStreamDestroy(c->stream);
+        delete c;
+        return -2;
+    }
     *out = c;
     return 0;
 }
@@ -174,6 +188,34 @@ extern "C" int semz_decode_batch_device(semz_ctx *c, uint32_t kind, const void *
     default:
         return semz_fail(c, -1, "unknown unit kind %u", kind);
     }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// Same as semz_decode_batch_device for the deflate family, without any allocation: no hipMalloc / hipFree, no
+// event creation ("profile" spans are not recorded), the tail table lives in this GPU's static scratch array.
+// Every call on one GPU shares that array: calls that overlap on one GPU (two contexts, two streams) race.
+extern "C" int semz_decode_batch_device_noalloc(semz_ctx *c, uint32_t kind, const void *d_in, size_t in_len,
+                                                const semz_unit *d_units, size_t nunits, void *d_out,
+                                                size_t out_cap, semz_result *d_results)
+{
+    if (!c) return -1;
+    if (nunits == 0) return 0;
+    if (!d_in || !d_units || !d_out || !d_results) return semz_fail(c, -1, "null device pointer");
+    if (kind > SEMZ_UNIT_GZIP)
+        return semz_fail(c, -1, "semz_decode_batch_device_noalloc decodes deflate / zlib / gzip units only (kind %u needs "
+                                "per-batch scratch: use semz_decode_batch_device)", kind);
+    if (nunits > SEMZ_NOALLOC_MAX_UNITS)
+        return semz_fail(c, -1, "semz_decode_batch_device_noalloc takes at most %zu units per call (got %zu): split the batch",
+                         SEMZ_NOALLOC_MAX_UNITS, nunits);
+    HIPCHK(c, hipSetDevice(c->device));
+    semz_tail *tails = (semz_tail *)c->noalloc_scratch;          // the device address, never the symbol's name
+    // the array keeps the last call's contents: the records of this call start from zero
+    HIPCHK(c, hipMemsetAsync(tails, 0, nunits * sizeof(semz_tail), c->stream));
+    semz_launch_inflate((const uint8_t *)d_in, in_len, d_units, (uint32_t)nunits, (uint8_t *)d_out, out_cap,
+                        d_results, tails, c->stream);
+    semz_launch_checksum((const uint8_t *)d_out, d_units, (uint32_t)nunits, d_results, tails,
+                         c->d_tabs, (1u << SEMZ_TK_CRC32) | (1u << SEMZ_TK_ADLER32), c->stream);
     HIPCHK(c, hipGetLastError());
     return 0;
 }

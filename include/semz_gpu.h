@@ -156,6 +156,20 @@ int semz_decode_batch(semz_ctx *ctx, const uint8_t *in, size_t in_len,
 int semz_decode_batch_device(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
                              const semz_unit *d_units, size_t nunits,
                              void *d_out, size_t out_cap, semz_result *d_results);
+/* No counterpart in the reference.  For callers that cannot allocate device
+ * memory while they decode (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): semz_decode_batch_device for the deflate
+ * family (SEMZ_UNIT_DEFLATE / ZLIB / GZIP) that calls no hipMalloc, hipFree or
+ * other allocating routine.  The per-unit trailer table that connects the
+ * inflate and checksum kernels lives in a static device array of the library
+ * (64 bytes per unit, 4 MiB per GPU) instead of grow-only scratch; at most
+ * SEMZ_NOALLOC_MAX_UNITS units per call, more is refused with -1 and a message.
+ * All calls on one GPU share that array: calls that overlap on one GPU race.
+ * Asynchronous on the context's stream like semz_decode_batch_device. */
+#define SEMZ_NOALLOC_MAX_UNITS 65536
+int semz_decode_batch_device_noalloc(semz_ctx *ctx, uint32_t kind, const void *d_in, size_t in_len,
+                                     const semz_unit *d_units, size_t nunits,
+                                     void *d_out, size_t out_cap, semz_result *d_results);
 /* Options: "profile" = 1 records a HIP event pair around every kernel of later calls.
  * "window-size" = the :window-size keyword of the :raw-lzma2 format (lzma2.lisp:206-218; values
  * above 2^32-1 are clipped as there), used by semz_decode_stream(SEMZ_FMT_RAW_LZMA2 / _RAW_LZMA).
