@@ -313,6 +313,9 @@ bool xz_blocks_from_index(const uint8_t *in, uint64_t in_len, std::vector<XzInde
             if (xz_varint(in, &p, end - 12, &b.unpadded) != SEMZ_OK) return false;
             if (xz_varint(in, &p, end - 12, &b.usize) != SEMZ_OK) return false;
             if (b.unpadded < 5 || b.unpadded > (1ull << 62)) return false;
+            // an LZMA2 chunk makes at most 2 MiB out of its 11 bytes and more: a record that promises more than that
+            // from the block's bytes is no prediction to allocate by (the forward walk reports the mismatch)
+            if (b.usize > (1ull << 62) || (b.unpadded < (1ull << 40) && b.usize > (b.unpadded << 18) + (1u << 21))) return false;
             b.check_type = check_type;
             total += (b.unpadded + 3) & ~3ull;
             if (total > idx_start) return false;
@@ -475,7 +478,9 @@ extern "C" int semz_split(int fmt, const uint8_t *in, size_t in_len, const uint6
             x.param2 = h.bcj_offset;
             x.param3 = h.delta_dists;
             x.filters = h.filters;
-            out_off += b.usize;
+            uint64_t next_off;
+            if (__builtin_add_overflow(out_off, b.usize, &next_off)) { n--; break; }   // (cannot happen with the bound above)
+            out_off = next_off;
         }
         si.total_out = out_off;
         si.nmembers = 1;

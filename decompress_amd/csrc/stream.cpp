@@ -59,13 +59,25 @@ struct Run {
         HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
         return 0;
     }
+    // Sizes that come out of the data (declared sizes, index records, ISIZE fields) are untrusted: a request the
+    // device cannot serve is RC_OOM, which the callers turn into "decode without the prediction" or into the
+    // per-stream status SEMZ_E_NO_MEMORY, never into a failed call.
+    static constexpr int RC_OOM = 1000;
     // room for `need` more bytes at the end of the arena; keeps what is there
     int reserve(size_t need)
     {
+        if (need > (SIZE_MAX >> 2) || out_used > (SIZE_MAX >> 2)) return RC_OOM;      // the sums below cannot wrap
         if (out_used + need + 64 <= out_cap) return 0;
         size_t ncap = (out_used + need + 64) * 3 / 2 + (1 << 20);
         uint8_t *n = nullptr;
-        HIPCHK(c, hipMalloc((void **)&n, ncap));
+        hipError_t e = hipMalloc((void **)&n, ncap);
+        if (e == hipErrorOutOfMemory) {                        // without the slack, then
+            (void)hipGetLastError();
+            ncap = out_used + need + 64;
+            e = hipMalloc((void **)&n, ncap);
+        }
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
+        HIPCHK(c, e);
         if (out_used) HIPCHK(c, hipMemcpyAsync(n, d_out, out_used, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (d_out) HIPCHK(c, hipFree(d_out));
@@ -79,6 +91,11 @@ struct Run {
         const size_t n = units.size();
         res.assign(n, semz_result{});
         if (!n) return 0;
+        // every fixed span must lie inside the room this call hands to the kernels (they check it again per unit)
+        if (arena_base > out_cap || arena_room > out_cap - arena_base) return semz_fail(c, -4, "internal: arena room beyond the arena");
+        for (auto &u : units)
+            if (u.out_off != SEMZ_OUT_AUTO && (u.out_off > arena_room || u.out_cap > arena_room - u.out_off))
+                return semz_fail(c, -4, "internal: unit span beyond the arena room");
         if (n > unit_cap) {
             if (d_units) HIPCHK(c, hipFree(d_units));
             if (d_res) HIPCHK(c, hipFree(d_res));
@@ -95,13 +112,22 @@ struct Run {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
-    // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP
-    int decode_one(semz_unit u, semz_result &r, uint64_t guess)
+    // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP.
+    // `limit` is the largest span that can be of use (a declared size, or what the format can expand to from the
+    // bytes that are left); a span the device cannot give is SEMZ_E_NO_MEMORY for the stream, not a failed call.
+    int decode_one(semz_unit u, semz_result &r, uint64_t guess, uint64_t limit)
     {
         std::vector<semz_unit> us(1);
         std::vector<semz_result> rs;
+        if (guess > limit) guess = limit;
         for (;;) {
             int rc = reserve(guess);
+            if (rc == RC_OOM) {
+                r = semz_result{};
+                r.status = SEMZ_E_NO_MEMORY;
+                r.in_end_bit = 8 * u.in_off + u.in_bit_off;
+                return 0;
+            }
             if (rc) return rc;
             u.out_off = u.out_off == SEMZ_OUT_AUTO ? SEMZ_OUT_AUTO : 0;
             u.out_cap = guess;
@@ -109,8 +135,8 @@ struct Run {
             rc = decode(us, rs, out_used, guess);
             if (rc) return rc;
             r = rs[0];
-            if (r.status != SEMZ_E_OUT_CAP || guess > (1ull << 40)) break;
-            guess *= 4;
+            if (r.status != SEMZ_E_OUT_CAP || guess >= limit) break;
+            guess = guess > limit / 4 ? limit : guess * 4;
         }
         r.out_off += out_used;                 // arena offset
         if (r.status == SEMZ_OK) out_used += r.out_len;
@@ -149,6 +175,12 @@ struct Run {
 
 struct Outcome { int status = SEMZ_OK; uint32_t detail = 0; uint64_t consumed = 0; };
 
+inline uint64_t sat_mul(uint64_t a, uint64_t b) { uint64_t r; return __builtin_mul_overflow(a, b, &r) ? ~0ull : r; }
+inline uint64_t sat_add(uint64_t a, uint64_t b) { uint64_t r; return __builtin_add_overflow(a, b, &r) ? ~0ull : r; }
+// what `rem` bytes of input can expand to at most
+inline uint64_t deflate_bound(uint64_t rem) { return sat_add(sat_mul(rem, 1032), 1024); }     // 258 bytes per two bits
+inline uint64_t lzma_bound(uint64_t rem) { return sat_add(sat_mul(rem, 1ull << 18), 1 << 21); } // 2 MiB per 11-byte LZMA2 chunk
+
 // ---- deflate / zlib / gzip ----
 int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *info)
 {
@@ -160,19 +192,33 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
         size_t sn = 0;
         semz_stream_info si;
         if (semz_split(fmt, R.in, R.in_len, nullptr, nullptr, 0, &su, &sn, &si) == 0 && si.reserved > 1) {
-            std::vector<semz_unit> units(su, su + si.reserved);   // members whose size the BGZF index gives
+            // members whose size the BGZF index gives.  The spans come from the members' ISIZE fields, which are
+            // only hypotheses: one that deflate cannot reach from the member's bytes is left to the walk below,
+            // and so is a member that overflows its span (SEMZ_E_OUT_CAP is not a condition of the reference:
+            // decoded alone the member gets the trailer error the reference reports).
+            std::vector<semz_unit> units;
             uint64_t total = 0;
-            for (auto &u : units) total += u.out_cap;
-            int rc = R.reserve(total);
-            if (rc) { free(su); return rc; }
-            std::vector<semz_result> res;
-            rc = R.decode(units, res, R.out_used, total);
-            if (rc) { free(su); return rc; }
-            for (size_t i = 0; i < units.size(); i++) {
-                res[i].out_off += R.out_used;
-                pre[units[i].in_off] = res[i];
+            for (size_t i = 0; i < si.reserved; i++) {
+                semz_unit u = su[i];
+                const uint64_t next = i + 1 < sn ? su[i + 1].in_off : R.in_len;
+                if (u.out_cap > deflate_bound(next - u.in_off)) continue;
+                u.out_off = total;
+                total += u.out_cap;                               // back to back: the stream's output stays one span
+                units.push_back(u);
             }
-            R.out_used += total;
+            int rc = units.size() > 1 ? R.reserve(total) : Run::RC_OOM;
+            if (rc && rc != Run::RC_OOM) { free(su); return rc; }
+            if (rc == 0) {
+                std::vector<semz_result> res;
+                rc = R.decode(units, res, R.out_used, total);
+                if (rc) { free(su); return rc; }
+                for (size_t i = 0; i < units.size(); i++) {
+                    if (res[i].status == SEMZ_E_OUT_CAP) continue;
+                    res[i].out_off += R.out_used;
+                    pre[units[i].in_off] = res[i];
+                }
+                R.out_used += total;
+            }
         }
         free(su);
         if (pre.empty()) {
@@ -200,7 +246,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                     if (span < 18) continue;
                     const uint64_t isize = (uint64_t)in[next - 4] | (uint64_t)in[next - 3] << 8 | (uint64_t)in[next - 2] << 16 |
                                            (uint64_t)in[next - 1] << 24;
-                    if (isize > 1032 * span) continue;               // deflate cannot expand further: not a member end
+                    if (isize > deflate_bound(span)) continue;       // deflate cannot expand further: not a member end
                     semz_unit u{};
                     u.kind = SEMZ_UNIT_GZIP;
                     u.in_off = cand[i];
@@ -212,9 +258,9 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                 }
                 // (look-alike headers in a large single member can hypothesise gigabytes each: speculation is only
                 // worth a bounded amount of memory, otherwise the members are decoded one after the other)
-                if (units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len)) {
-                    int rc = R.reserve(total);
-                    if (rc) return rc;
+                int rc = units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len) ? R.reserve(total) : Run::RC_OOM;
+                if (rc && rc != Run::RC_OOM) return rc;
+                if (rc == 0) {
                     std::vector<semz_result> res;
                     rc = R.decode(units, res, R.out_used, total);
                     if (rc) return rc;
@@ -239,7 +285,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
             u.in_off = pos;
             u.in_limit = R.in_len;
             uint64_t guess = (R.in_len - pos) * 6 + 65536;
-            int rc = R.decode_one(u, r, guess);
+            int rc = R.decode_one(u, r, guess, deflate_bound(R.in_len - pos));
             if (rc) return rc;
         }
         if (member == 0 && info) {
@@ -281,13 +327,14 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
     uint64_t arena0 = R.out_used;
     for (;;) {
         int rc = R.reserve(guess);
+        if (rc == Run::RC_OOM) { oc.status = SEMZ_E_NO_MEMORY; return 0; }
         if (rc) return rc;
         rc = R.decode(units, res, arena0, guess);
         if (rc) return rc;
         bool cap = false;
         for (auto &r : res) cap = cap || r.status == SEMZ_E_OUT_CAP;
-        if (!cap || guess > (1ull << 40)) break;
-        guess *= 4;                                               // RLE1 can expand far beyond the block size
+        if (!cap) break;
+        guess = sat_mul(guess, 4);                                // RLE1 can expand far beyond the block size
     }
     for (size_t i = 0; i < units.size(); i++) {
         by_bit[start_bits[i]] = i;
@@ -323,7 +370,7 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
                     u.in_limit = R.in_len;
                     u.out_off = SEMZ_OUT_AUTO;
                     u.param0 = level;
-                    int rc = R.decode_one(u, r, (uint64_t)level * 100000 * 2);
+                    int rc = R.decode_one(u, r, (uint64_t)level * 100000 * 2, (uint64_t)level * 100000 * 52 + 1024);   // RLE1: 5 bytes -> 259
                     if (rc) return rc;
                 }
                 if (r.status != SEMZ_OK) {
@@ -363,17 +410,22 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
         size_t sn = 0;
         semz_stream_info si;
         if (semz_split(SEMZ_FMT_XZ, R.in, R.in_len, nullptr, nullptr, 0, &su, &sn, &si) == 0 && sn) {
+            // The index is a prediction, not a fact: semz_split bounds every record by what LZMA2 can expand to
+            // and the sum cannot wrap; an arena the device cannot give means "no prediction" (the walk below then
+            // decodes block by block and reports what the reference would, an index mismatch at the end).
             std::vector<semz_unit> units(su, su + sn);
             int rc = R.reserve(si.total_out);
-            if (rc) { free(su); return rc; }
-            std::vector<semz_result> res;
-            rc = R.decode(units, res, R.out_used, si.total_out);
-            if (rc) { free(su); return rc; }
-            for (size_t i = 0; i < sn; i++) {
-                res[i].out_off += R.out_used;
-                pre[units[i].in_off] = std::make_pair(units[i], res[i]);
+            if (rc && rc != Run::RC_OOM) { free(su); return rc; }
+            if (rc == 0) {
+                std::vector<semz_result> res;
+                rc = R.decode(units, res, R.out_used, si.total_out);
+                if (rc) { free(su); return rc; }
+                for (size_t i = 0; i < sn; i++) {
+                    res[i].out_off += R.out_used;
+                    pre[units[i].in_off] = std::make_pair(units[i], res[i]);
+                }
+                R.out_used += si.total_out;
             }
-            R.out_used += si.total_out;
         }
         free(su);
     }
@@ -415,13 +467,17 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
             }
             if (reuse) r = it->second.second;
             else {
-                uint64_t guess = h.have_usize && h.usize < (1ull << 40) ? h.usize : (n - data) * 8 + (1 << 20);
-                int rc = R.decode_one(u, r, guess);
+                // a declared size is a hint for the span, never more than LZMA2 can make of the bytes that are left;
+                // the first span is modest and grows while the block asks for more
+                const uint64_t bound = lzma_bound(n - data);
+                const uint64_t first = sat_add(sat_mul(n - data, 64), 1 << 20);
+                uint64_t limit = h.have_usize && h.usize < bound ? h.usize : bound;
+                int rc = R.decode_one(u, r, std::min(first, limit), limit);
                 if (rc) return rc;
-                if (r.status == SEMZ_E_OUT_CAP && h.have_usize) {
+                if (r.status == SEMZ_E_OUT_CAP && limit < bound) {
                     // the declared size was too small for what the block holds: decode on to find the
                     // error the reference reports (a size mismatch at block end, or an earlier one)
-                    rc = R.decode_one(u, r, (n - data) * 8 + (1 << 20));
+                    rc = R.decode_one(u, r, first, bound);
                     if (rc) return rc;
                 }
             }
@@ -521,7 +577,7 @@ int run_lzma2(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *
     u.kind = SEMZ_UNIT_LZMA2;
     u.param0 = dict;
     semz_result r{};
-    int rc = R.decode_one(u, r, std::max<uint64_t>(1 << 20, 8 * R.in_len));
+    int rc = R.decode_one(u, r, std::max<uint64_t>(1 << 20, sat_mul(8, R.in_len)), lzma_bound(R.in_len));
     if (rc) return rc;
     oc.consumed = (r.in_end_bit + 7) / 8;
     if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
@@ -540,7 +596,7 @@ int run_lzma(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *i
 {
     semz_unit u{};
     u.in_limit = R.in_len;
-    uint64_t guess = std::max<uint64_t>(1 << 20, 8 * R.in_len);
+    uint64_t guess = std::max<uint64_t>(1 << 20, sat_mul(8, R.in_len));
     if (fmt == SEMZ_FMT_LZMA) {
         if (R.in_len < 1) { oc.status = SEMZ_EOF; return 0; }
         const uint32_t octet = R.in[0];                      // parse-lzma-props, lzma.lisp:837-843
@@ -572,9 +628,15 @@ int run_lzma(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *i
     }
     const uint32_t lclp = (u.param1 & 0xFF) + ((u.param1 >> 8) & 0xFF);
     u.kind = lclp > 4 ? SEMZ_UNIT_LZMA_WIDE : SEMZ_UNIT_LZMA;
-    if ((u.flags & SEMZ_UF_HAVE_OUT_SIZE) && u.size_out < (1ull << 36)) guess = std::max<uint64_t>(u.size_out, 1);
+    // raw LZMA has no chunk limit: a match of 273 bytes costs a fraction of a bit, so only memory bounds the
+    // output; a declared size caps the span but never sizes the first attempt by itself
+    uint64_t limit = ~0ull >> 3;
+    if (u.flags & SEMZ_UF_HAVE_OUT_SIZE) {
+        limit = std::max<uint64_t>(u.size_out, 1);
+        guess = std::min(limit, std::max<uint64_t>(guess, sat_mul(64, R.in_len)));
+    }
     semz_result r{};
-    int rc = R.decode_one(u, r, guess);
+    int rc = R.decode_one(u, r, guess, limit);
     if (rc) return rc;
     oc.consumed = (r.in_end_bit + 7) / 8;
     if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }

@@ -140,6 +140,9 @@ typedef enum semz_status {
     SEMZ_E_OUT_CAP = 200,              /* unit produced more than its out_cap: retry with a larger span */
     SEMZ_E_UNSUPPORTED = 201,          /* unit uses a feature outside the current hot-path scope */
     SEMZ_E_NOT_RUN = 202,              /* unit was not decoded (an earlier unit in its chain failed) */
+    SEMZ_E_NO_MEMORY = 204,            /* semz_decode_stream: the size the data asks for (a declared size, or what a
+                                          unit keeps expanding to) does not fit the device memory the engine can get;
+                                          the reference streams in bounded memory and would go on (common.lisp:255-257) */
     SEMZ_E_BAD_UNIT = 203              /* semz_decode_batch_device: the unit's spans leave the buffers of the call
                                           (in_limit > in_len, out_off + out_cap > out_cap, prefix outside `in`),
                                           or its kind does not belong to the batch's family; nothing was read or written */

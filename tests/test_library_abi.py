@@ -43,7 +43,7 @@ def test_strerror_texts():
     assert _lib.strerror(170) == "Trailing data detected."
     for code in list(range(0, 2)) + list(range(10, 12)) + list(range(20, 29)) + list(range(40, 46)) + \
             list(range(50, 57)) + list(range(60, 76)) + list(range(80, 94)) + list(range(100, 108)) + \
-            list(range(120, 157)) + [170, 200, 201, 202, 203]:
+            list(range(120, 157)) + [170, 200, 201, 202, 203, 204]:
         assert _lib.strerror(code) and "unknown status" not in _lib.strerror(code).lower(), code
 
 

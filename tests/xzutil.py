@@ -75,3 +75,64 @@ def xz_single_block(filtered, plain, filter_id, crc64):
     index = with_crc(index + b"\0" * (-len(index) % 4))
     footer = ((len(index) // 4) - 1).to_bytes(4, "little") + flags
     return header + block + index + zlib.crc32(footer).to_bytes(4, "little") + footer + b"YZ"
+
+
+def varint(v):
+    out = bytearray()
+    while True:
+        out.append(v & 0x7F)
+        v >>= 7
+        if not v:
+            return bytes(out)
+        out[-1] |= 0x80
+
+
+def xz_rewrite_index(data, records=None, edit=None):
+    """A single-stream .xz with its index replaced: `records` = [(unpadded size, uncompressed size)], or
+    `edit` = a function old records -> new records.  Index CRC, backward size and footer CRC are made
+    consistent, so only the forward walk (xz.lisp:186-203) can tell that the index lies."""
+    import zlib
+    footer = data[-12:]
+    assert footer[-2:] == b"YZ"
+    bsize = 4 * (int.from_bytes(footer[4:8], "little") + 1)
+    idx0 = len(data) - 12 - bsize
+    if records is None:
+        p = idx0 + 1
+        def rd():
+            nonlocal p
+            v, sh = 0, 0
+            while True:
+                b = data[p]; p += 1
+                v |= (b & 0x7F) << sh; sh += 7
+                if not b & 0x80:
+                    return v
+        old = [(rd(), rd()) for _ in range(rd())]
+        records = edit(old)
+    index = b"\x00" + varint(len(records)) + b"".join(varint(a) + varint(b) for a, b in records)
+    index += b"\0" * (-len(index) % 4)
+    index += zlib.crc32(index).to_bytes(4, "little")
+    tail = ((len(index) // 4) - 1).to_bytes(4, "little") + footer[8:10]
+    return data[:idx0] + index + zlib.crc32(tail).to_bytes(4, "little") + tail + b"YZ"
+
+
+def xz_block_with_declared_sizes(plain, csize=None, usize=None, check=b"\x00\x01"):
+    """A one-block .xz stream whose block header declares the given compressed / uncompressed sizes
+    (None = field absent), whatever the block really holds.  CRC32 check by default."""
+    import zlib
+
+    def with_crc(body):
+        return body + zlib.crc32(body).to_bytes(4, "little")
+
+    raw = lzma.compress(plain, lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": 6, "dict_size": 1 << 20}])
+    flags = (0x40 if csize is not None else 0) | (0x80 if usize is not None else 0)
+    body = bytes([flags]) + (varint(csize) if csize is not None else b"") + (varint(usize) if usize is not None else b"")
+    body += bytes([0x21, 0x01, 16])
+    total = (len(body) + 1 + 3) & ~3
+    bh = bytes([total // 4]) + body + b"\0" * (total - 1 - len(body))
+    chk = zlib.crc32(plain).to_bytes(4, "little")
+    block = with_crc(bh) + raw + b"\0" * (-len(raw) % 4) + chk
+    header = b"\xfd7zXZ\x00" + with_crc(check)
+    index = b"\x00" + varint(1) + varint(len(bh) + 4 + len(raw) + 4) + varint(len(plain))
+    index = with_crc(index + b"\0" * (-len(index) % 4))
+    footer = ((len(index) // 4) - 1).to_bytes(4, "little") + check
+    return header + block + index + zlib.crc32(footer).to_bytes(4, "little") + footer + b"YZ"
