@@ -33,6 +33,10 @@ class Result(C.Structure):
     ]
 
 
+class Member(C.Structure):
+    _fields_ = [("in_end", C.c_uint64), ("out_end", C.c_uint64)]
+
+
 class StreamInfo(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("detail", C.c_uint32), ("total_out", C.c_uint64),
@@ -58,6 +62,7 @@ EXPORTS = [
     "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
     "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
     "semz_split", "semz_free", "semz_decode_stream",
+    "semz_stream_decode", "semz_stream_members", "semz_stream_read", "semz_stream_release", "semz_decode_stream_into",
     "semz_profile_count", "semz_profile_get", "semz_profile_reset",
 ]
 
@@ -103,6 +108,14 @@ def load():
     lib.semz_decode_stream.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int,
                                        C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(Result),
                                        C.POINTER(StreamInfo)]
+    lib.semz_stream_decode.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(vp),
+                                       C.POINTER(Result), C.POINTER(StreamInfo)]
+    lib.semz_stream_members.argtypes = [vp, C.POINTER(C.POINTER(Member)), C.POINTER(C.c_size_t)]
+    lib.semz_stream_read.argtypes = [vp, C.c_uint64, vp, C.c_size_t]
+    lib.semz_stream_release.argtypes = [vp]
+    lib.semz_stream_release.restype = None
+    lib.semz_decode_stream_into.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.c_int, vp, C.c_size_t,
+                                            C.POINTER(C.c_size_t), C.POINTER(Result), C.POINTER(StreamInfo)]
     lib.semz_profile_count.argtypes = [vp]
     lib.semz_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float)]
     lib.semz_profile_reset.argtypes = [vp]
@@ -209,6 +222,21 @@ class Engine:
             self.lib.semz_profile_reset(self.h)
         return out
 
+    def stream_decode(self, fmt, data, all_members=True):
+        return Decoded(self, fmt, data, all_members)
+
+    def decode_stream_into(self, fmt, data, out_buf, all_members=True):
+        """decompress-all into a caller-owned ctypes buffer. Returns (rc, out_len, Result, StreamInfo); rc 1 = too small."""
+        out_len = C.c_size_t()
+        res = Result()
+        info = StreamInfo()
+        rc = self.lib.semz_decode_stream_into(self.h, fmt, bytes(data), len(data), 1 if all_members else 0,
+                                              C.cast(out_buf, C.c_void_p), C.sizeof(out_buf), C.byref(out_len),
+                                              C.byref(res), C.byref(info))
+        if rc not in (0, 1):
+            self._chk(rc)
+        return rc, out_len.value, res, info
+
     def decode_stream(self, fmt, data, all_members=True):
         """decompress / decompress-all on the GPU. Returns (bytes, Result, StreamInfo)."""
         out = C.c_void_p()
@@ -223,6 +251,40 @@ class Engine:
             if out.value:
                 self.lib.semz_free(out)
         return payload, res, info
+
+
+class Decoded:
+    """A decoded stream held in device memory (semz_stream_decode): members, ranged reads, release."""
+
+    def __init__(self, engine, fmt, data, all_members=True):
+        self.engine = engine
+        self.res = Result()
+        self.info = StreamInfo()
+        h = C.c_void_p()
+        engine._chk(engine.lib.semz_stream_decode(engine.h, fmt, bytes(data), len(data), 1 if all_members else 0,
+                                                  C.byref(h), C.byref(self.res), C.byref(self.info)))
+        self.h = h
+        m = C.POINTER(Member)()
+        n = C.c_size_t()
+        engine._chk(engine.lib.semz_stream_members(self.h, C.byref(m), C.byref(n)))
+        self.members = [(m[i].in_end, m[i].out_end) for i in range(n.value)]
+        self.out_len = self.res.out_len
+
+    def read(self, offset, length):
+        buf = C.create_string_buffer(max(length, 1))
+        self.engine._chk(self.engine.lib.semz_stream_read(self.h, offset, buf, length))
+        return buf.raw[:length]
+
+    def release(self):
+        if self.h:
+            self.engine.lib.semz_stream_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def strerror(status):

@@ -102,8 +102,19 @@ def _header(fmt, data, res, info):
     if fmt == "gzip":
         def field(off, ln):
             return data[off:off + ln].decode("latin-1") if off != 0xFFFFFFFF else None
-        return {"textp": bool(h[0]), "extra_fields": None, "filename": field(h[4], h[5]), "comment": field(h[6], h[7]),
-                "modification_time": h[1], "extra_flags": h[2], "operating_system": h[3]}
+
+        def extra_fields(off, ln):                        # parse-gzip-extra-fields, gzip.lisp:23-29: ((id . bytes) ...)
+            if off == 0xFFFFFFFF:
+                return []
+            raw, out, i = data[off:off + ln], [], 0
+            while i < len(raw):
+                n = int.from_bytes(raw[i + 2:i + 4], "little")
+                out.append((raw[i:i + 2].decode("latin-1"), raw[i + 4:i + 4 + n]))
+                i += 4 + n
+            return out
+        return {"textp": bool(h[0] & 1), "extra_fields": extra_fields(h[2], h[3]), "filename": field(h[4], h[5]),
+                "comment": field(h[6], h[7]), "modification_time": h[1], "extra_flags": (h[0] >> 8) & 0xFF,
+                "operating_system": (h[0] >> 16) & 0xFF}
     if fmt == "bzip2":
         return {"block_size": 100000 * h[0]}
     if fmt == "xz":
@@ -203,15 +214,19 @@ def decompress_all(format, input, **kw):
     return decompress(format, input, **kw)
 
 
-class DecompressionStream(io.BytesIO):
+class DecompressionStream(io.RawIOBase):
     """`decompression-stream` (interface.lisp:8-44): a readable binary stream of the decoded data.
 
-    The reference decodes lazily chunk by chunk; this engine decodes whole units on the GPU at
-    construction.  An error in the data is raised by the read that would reach the failing unit,
-    after the bytes of the units before it have been delivered (interface.lisp:105-108).
+    The reference decodes lazily chunk by chunk.  This engine decodes all units on the GPU when the
+    stream is made, keeps the result in device memory (semz_stream_decode) and hands it out member by
+    member as it is read (semz_stream_members / semz_stream_read): exactly what the `gpu-batch-state`
+    of lisp/gpu.lisp does behind `next-decompressed-chunk` / `make-reset-state`.  An error in the data
+    is raised by the read that would reach the failing member, after the bytes of the members before
+    it have been delivered (interface.lisp:105-108).
     """
 
     def __init__(self, format, input, all_members_p=False, **kw):
+        super().__init__()
         if hasattr(input, "read"):
             data = input.read()
         else:
@@ -220,19 +235,36 @@ class DecompressionStream(io.BytesIO):
         if format not in FORMATS:
             raise ValueError(f"unknown format {format!r}; supported: {list_supported_formats()}")
         _format_options(format, kw.get("window_size"), kw)
-        payload, res, info = _get_engine().decode_stream(FORMATS[format], data, all_members_p)
+        self._d = _get_engine().stream_decode(FORMATS[format], data, all_members_p)
+        res = self._d.res
         self._pending = None if res.status == 0 else (res.status, res.detail)
-        self.header = _header(format, data, res, info)
-        super().__init__(payload)
+        self.header = _header(format, data, res, self._d.info)
+        self._pos = 0
+        self._len = self._d.out_len
+
+    def readable(self):
+        return True
 
     def read(self, size=-1):
-        chunk = super().read(size)
-        if self._pending and (size is None or size < 0 or len(chunk) < size):
+        left = self._len - self._pos
+        n = left if size is None or size < 0 else min(size, left)
+        chunk = self._d.read(self._pos, n) if n else b""
+        self._pos += n
+        if self._pending and (size is None or size < 0 or n < size) and not chunk:
             st, self._pending = self._pending, None
-            if not chunk:
-                _raise(*st)
-            self._pending = st
+            self._d.release()
+            _raise(*st)
         return chunk
+
+    def readinto(self, b):
+        chunk = self.read(len(b))
+        b[:len(chunk)] = chunk
+        return len(chunk)
+
+    def close(self):
+        if getattr(self, "_d", None) is not None:
+            self._d.release()
+        super().close()
 
 
 def make_decompression_stream(format, input, **kw):

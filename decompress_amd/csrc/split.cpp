@@ -415,7 +415,9 @@ extern "C" int semz_split(int fmt, const uint8_t *in, size_t in_len, const uint6
             GzipHeader h = parse_gzip_header(in, 0, in_len);
             si.status = h.status;
             si.detail = h.detail;
-            si.first_header[0] = h.textp; si.first_header[1] = h.mtime; si.first_header[2] = h.xfl; si.first_header[3] = h.os;
+            // textp | extra flags << 8 | operating system << 16; mtime; extra field span; name span; comment span
+            si.first_header[0] = h.textp | (h.xfl << 8) | (h.os << 16); si.first_header[1] = h.mtime;
+            si.first_header[2] = (uint32_t)h.extra_off; si.first_header[3] = (uint32_t)h.extra_len;
             si.first_header[4] = (uint32_t)h.name_off; si.first_header[5] = (uint32_t)h.name_len;
             si.first_header[6] = (uint32_t)h.comment_off; si.first_header[7] = (uint32_t)h.comment_len;
         } else if (fmt == SEMZ_FMT_ZLIB && in_len >= 2) {

@@ -44,6 +44,8 @@ struct Run {
     semz_result *d_res = nullptr;
     size_t unit_cap = 0;
     std::vector<Span> spans;                   // output of the stream, in order, as arena spans
+    uint64_t emitted = 0;                      // bytes in `spans`
+    std::vector<semz_member> members;          // members the walk has completed, in order
 
     ~Run()
     {
@@ -142,16 +144,43 @@ struct Run {
         if (r.status == SEMZ_OK) out_used += r.out_len;
         return 0;
     }
+    void member_done(uint64_t in_end) { members.push_back(semz_member{in_end, emitted}); }
+    // what only the decode needs: the input copy and the unit tables (the arena stays for semz_stream_read)
+    void drop_working_set()
+    {
+        if (d_in) (void)hipFree(d_in);
+        if (d_units) (void)hipFree(d_units);
+        if (d_res) (void)hipFree(d_res);
+        d_in = nullptr; d_units = nullptr; d_res = nullptr; unit_cap = 0;
+        in = nullptr;                          // no host pointer is kept beyond the call
+    }
+    // bytes [off, off + len) of the decoded stream into dst (host memory)
+    int read(uint64_t off, uint8_t *dst, uint64_t len)
+    {
+        if (off > emitted || len > emitted - off) return semz_fail(c, -1, "semz_stream_read: range beyond the decoded stream");
+        uint64_t at = 0;
+        for (auto &sp : spans) {
+            if (!len) break;
+            if (off < at + sp.len) {
+                const uint64_t skip = off - at, take = std::min<uint64_t>(len, sp.len - skip);
+                HIPCHK(c, hipMemcpyAsync(dst, d_out + sp.off + skip, take, hipMemcpyDeviceToHost, c->stream));
+                dst += take; off += take; len -= take;
+            }
+            at += sp.len;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
     void emit(uint64_t off, uint64_t len)
     {
         if (!len) return;
+        emitted += len;
         if (!spans.empty() && spans.back().off + spans.back().len == off) spans.back().len += len;
         else spans.push_back(Span{off, len});
     }
     int gather(uint8_t **out, size_t *out_len)
     {
-        size_t total = 0;
-        for (auto &s : spans) total += s.len;
+        const size_t total = emitted;
         // large results: 2 MiB alignment and a huge-page hint, so that the first touch of a fresh gigabyte does not
         // cost a page fault per 4 KiB (the download is otherwise bound by them); still released with free()
         uint8_t *h;
@@ -160,13 +189,8 @@ struct Run {
             if (h) madvise(h, total, MADV_HUGEPAGE);
         } else h = (uint8_t *)malloc(total ? total : 1);
         if (!h) return semz_fail(c, -5, "out of host memory (%zu bytes)", total);
-        size_t at = 0;
-        for (auto &s : spans) {
-            hipError_t e = hipMemcpyAsync(h + at, d_out + s.off, s.len, hipMemcpyDeviceToHost, c->stream);
-            if (e != hipSuccess) { free(h); return semz_fail(c, -2, "download: %s", hipGetErrorString(e)); }
-            at += s.len;
-        }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { free(h); return semz_fail(c, -2, "sync failed"); }
+        int rc = read(0, h, total);
+        if (rc) { free(h); return rc; }
         *out = h;
         *out_len = total;
         return 0;
@@ -295,6 +319,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
         oc.consumed = pos + ((r.in_end_bit - 8 * pos + 7) >> 3);
         if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
         R.emit(r.out_off, r.out_len);
+        R.member_done(oc.consumed);
         if (info) info->nmembers = member + 1;
         pos = oc.consumed;
         if (!all_members || pos == R.in_len) return 0;            // buffer-stream-check-eof, interface.lisp:110-112
@@ -395,6 +420,7 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
         }
         pos = (bit + 7) >> 3;                                     // flush-byte, bzip2.lisp:497
         oc.consumed = pos;
+        R.member_done(pos);
         if (info) info->nmembers = member + 1;
         if (!all_members || pos == R.in_len) return 0;
     }
@@ -535,6 +561,7 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
             (void)idx0;
         }
         oc.consumed = pos;
+        R.member_done(pos);
         if (info) info->nmembers = member + 1;
         if (!all_members || pos == n) return 0;
         // make-reset-state: stream padding, then the next member (xz.lisp:118-134)
@@ -582,6 +609,7 @@ int run_lzma2(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *
     oc.consumed = (r.in_end_bit + 7) / 8;
     if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
     R.emit(r.out_off, r.out_len);
+    R.member_done(oc.consumed);
     if (info) info->nmembers = 1;
     if (all_members && oc.consumed != R.in_len) oc.status = SEMZ_E_TRAILING_DATA;       // interface.lisp:125-130
     return 0;
@@ -641,6 +669,7 @@ int run_lzma(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *i
     oc.consumed = (r.in_end_bit + 7) / 8;
     if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
     R.emit(r.out_off, r.out_len);
+    R.member_done(oc.consumed);
     if (info) info->nmembers = 1;
     if (all_members && oc.consumed != R.in_len) oc.status = SEMZ_E_TRAILING_DATA;       // interface.lisp:125-130
     return 0;
@@ -648,23 +677,32 @@ int run_lzma(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *i
 
 }  // namespace
 
-extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t **out,
-                                  size_t *out_len, semz_result *res, semz_stream_info *info)
+struct semz_decoded { Run run; };
+
+extern "C" void semz_stream_release(semz_decoded *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->run.c->device);
+    delete d;
+}
+
+extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members,
+                                  semz_decoded **decoded, semz_result *res, semz_stream_info *info)
 {
     if (!c) return -1;
-    if (!out || !out_len || !res || (!in && in_len)) return semz_fail(c, -1, "null pointer");
-    *out = nullptr;
-    *out_len = 0;
+    if (!decoded || !res || (!in && in_len)) return semz_fail(c, -1, "null pointer");
+    *decoded = nullptr;
     memset(res, 0, sizeof *res);
     semz_stream_info si;
     memset(&si, 0, sizeof si);
-    // SEMZ_TRACE=1 prints where the call's wall time goes (upload, split + kernels, download)
+    // SEMZ_TRACE=1 prints where the call's wall time goes
     const bool trace = getenv("SEMZ_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    Run R{c, in, in_len};
+    semz_decoded *Rp = new semz_decoded{Run{c, in, in_len}};
+    Run &R = Rp->run;
     int rc = R.open();
-    if (rc) return rc;
+    if (rc) { delete Rp; return rc; }
     const double t1 = now();
     Outcome oc;
     switch (fmt) {
@@ -685,18 +723,78 @@ extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_
     case SEMZ_FMT_LZMA: rc = run_lzma(R, fmt, all_members != 0, oc, &si); break;
     case SEMZ_FMT_RAW_LZMA2:
     case SEMZ_FMT_LZMA2: rc = run_lzma2(R, fmt, all_members != 0, oc, &si); break;
-    default: return semz_fail(c, -1, "format %d has no stream decoder yet", fmt);
+    default: rc = semz_fail(c, -1, "format %d has no stream decoder", fmt); break;
     }
-    if (rc) return rc;
-    const double t2 = now();
-    rc = R.gather(out, out_len);
-    if (rc) return rc;
-    if (trace) fprintf(stderr, "semz_decode_stream: open+upload %.1f ms, split+decode %.1f ms, download %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
+    if (rc) { delete Rp; return rc; }
+    R.drop_working_set();
+    if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms\n", t1 - t0, now() - t1);
     res->status = oc.status;
     res->detail = oc.detail;
     res->in_end_bit = 8 * oc.consumed;
-    res->out_len = *out_len;
-    si.total_out = *out_len;
+    res->out_len = R.emitted;
+    si.total_out = R.emitted;
     if (info) *info = si;
+    *decoded = Rp;
     return 0;
+}
+
+extern "C" int semz_stream_members(const semz_decoded *d, const semz_member **members, size_t *nmembers)
+{
+    if (!d || !members || !nmembers) return -1;
+    *members = d->run.members.data();
+    *nmembers = d->run.members.size();
+    return 0;
+}
+
+extern "C" int semz_stream_read(semz_decoded *d, uint64_t offset, void *dst, size_t len)
+{
+    if (!d) return -1;
+    semz_ctx *c = d->run.c;
+    if (!dst && len) return semz_fail(c, -1, "null pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    return d->run.read(offset, (uint8_t *)dst, len);
+}
+
+extern "C" int semz_decode_stream_into(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members,
+                                       uint8_t *out, size_t out_cap, size_t *out_len, semz_result *res,
+                                       semz_stream_info *info)
+{
+    if (!c) return -1;
+    if (!out_len || (!out && out_cap)) return semz_fail(c, -1, "null pointer");
+    *out_len = 0;
+    semz_decoded *d = nullptr;
+    int rc = semz_stream_decode(c, fmt, in, in_len, all_members, &d, res, info);
+    if (rc) return rc;
+    Run *R = &d->run;
+    *out_len = R->emitted;
+    if (R->emitted > out_cap) {                          // the caller learns the size and decodes again, or uses the stepwise calls
+        semz_stream_release(d);
+        return 1;
+    }
+    const bool trace = getenv("SEMZ_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    rc = R->read(0, out, R->emitted);
+    if (trace) fprintf(stderr, "semz_decode_stream_into: download %.1f ms\n", now() - t0);
+    semz_stream_release(d);
+    return rc;
+}
+
+extern "C" int semz_decode_stream(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t **out,
+                                  size_t *out_len, semz_result *res, semz_stream_info *info)
+{
+    if (!c) return -1;
+    if (!out || !out_len || !res || (!in && in_len)) return semz_fail(c, -1, "null pointer");
+    *out = nullptr;
+    *out_len = 0;
+    semz_decoded *d = nullptr;
+    int rc = semz_stream_decode(c, fmt, in, in_len, all_members, &d, res, info);
+    if (rc) return rc;
+    const bool trace = getenv("SEMZ_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    rc = d->run.gather(out, out_len);
+    if (trace) fprintf(stderr, "semz_decode_stream: download %.1f ms\n", now() - t0);
+    semz_stream_release(d);
+    return rc;
 }

@@ -238,6 +238,39 @@ int semz_decode_stream(semz_ctx *ctx, int fmt, const uint8_t *in, size_t in_len,
                        int all_members, uint8_t **out, size_t *out_len,
                        semz_result *res, semz_stream_info *info);
 
+/* The same in steps, for hosts that own the output buffer (a Lisp vector, a
+ * pinned buffer) or want the output member by member:
+ *   semz_stream_decode   decodes like semz_decode_stream and keeps the decoded
+ *                        stream in device memory behind a handle (release it
+ *                        with semz_stream_release before semz_close of its
+ *                        context; several handles may be alive at once)
+ *   semz_stream_members  the members the walk completed, in order: where each
+ *                        ends in the input and in the output.  This is what the
+ *                        next-decompressed-chunk / make-reset-state methods of a
+ *                        host binding hand out one member at a time
+ *                        (interface.lisp:91-133: a member's chunks are delivered
+ *                        before the next member's header is looked at).  The
+ *                        array belongs to the handle.
+ *   semz_stream_read     bytes [offset, offset + len) of the decoded stream into
+ *                        caller memory, straight from the device
+ *   semz_decode_stream_into = decode + read of everything + release, into a
+ *                        caller-owned buffer: no malloc'ed intermediate, no second
+ *                        copy.  Returns 1, with the size needed in *out_len and
+ *                        nothing copied, when out_cap is too small. */
+typedef struct semz_member {
+    uint64_t in_end;      /* bytes of the input consumed when the member ended */
+    uint64_t out_end;     /* bytes of the output produced when the member ended */
+} semz_member;
+typedef struct semz_decoded semz_decoded;
+int semz_stream_decode(semz_ctx *ctx, int fmt, const uint8_t *in, size_t in_len, int all_members,
+                       semz_decoded **decoded, semz_result *res, semz_stream_info *info);
+int semz_stream_members(const semz_decoded *decoded, const semz_member **members, size_t *nmembers);
+int semz_stream_read(semz_decoded *decoded, uint64_t offset, void *dst, size_t len);
+void semz_stream_release(semz_decoded *decoded);
+int semz_decode_stream_into(semz_ctx *ctx, int fmt, const uint8_t *in, size_t in_len, int all_members,
+                            uint8_t *out, size_t out_cap, size_t *out_len,
+                            semz_result *res, semz_stream_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,3 +112,81 @@ def test_lzma_formats():
     with pytest.raises(api.EOF):
         api.decompress("lzma", a[:40])
     assert {"lzma", "raw-lzma", "lzma2", "raw-lzma2"} <= set(api.list_supported_formats())
+
+
+def test_gzip_header_plist_with_extra_fields():
+    """(:textp :extra-fields :filename :comment :modification-time :extra-flags :operating-system), gzip.lisp:81-87;
+    :extra-fields is the alist of parse-gzip-extra-fields (gzip.lisp:23-29)."""
+    import zlib
+    d = corpus.text(300, seed=9)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = co.compress(d) + co.flush()
+    extra = b"BC\x02\x00\x12\x34" + b"zz\x00\x00" + b"Ap\x03\x00xyz"
+    h = b"\x1f\x8b\x08\x1d" + (1234567).to_bytes(4, "little") + b"\x02\x03"
+    h += len(extra).to_bytes(2, "little") + extra + b"foo\0" + b"a comment\0"
+    member = h + body + zlib.crc32(d).to_bytes(4, "little") + len(d).to_bytes(4, "little")
+    out, hdr = api.decompress_all("gzip", member + member)
+    assert out == d + d
+    assert hdr == {"textp": True, "extra_fields": [("BC", b"\x12\x34"), ("zz", b""), ("Ap", b"xyz")],
+                   "filename": "foo", "comment": "a comment", "modification_time": 1234567,
+                   "extra_flags": 2, "operating_system": 3}
+    _, hdr = api.decompress("gzip", GZ2)
+    assert hdr["extra_fields"] == [] and hdr["filename"] == "foo"
+    # through an offset view as well (the spans in first_header are relative to the decoded input)
+    out, hdr = api.decompress_all("gzip", b"junk!" + member, start=5)
+    assert out == d and hdr["extra_fields"][2] == ("Ap", b"xyz")
+
+
+def test_stream_hands_out_members_in_order():
+    """The state machine lisp/gpu.lisp runs behind next-decompressed-chunk / make-reset-state: members come out
+    one after the other from device memory; the error of member k is raised by the read that reaches it."""
+    import gzip
+    from decompress_amd import _lib
+    parts = [corpus.text(20000 + 3000 * i, seed=70 + i) for i in range(6)]
+    members = [gzip.compress(p, 6) for p in parts]
+    bad = bytearray(b"".join(members))
+    off = sum(len(m) for m in members[:4]) + len(members[4]) // 2
+    bad[off] ^= 0x20                                                 # damage inside member 4
+    eng = api._get_engine()
+    d = eng.stream_decode(_lib.FMT_GZIP, bytes(bad), True)
+    assert d.res.status != 0 and len(d.members) == 4
+    pos_in = pos_out = 0
+    for k, (in_end, out_end) in enumerate(d.members):
+        assert in_end == pos_in + len(members[k]) and out_end == pos_out + len(parts[k])
+        assert d.read(pos_out, out_end - pos_out) == parts[k]       # ranged reads straight from the device
+        pos_in, pos_out = in_end, out_end
+    assert d.out_len == pos_out
+    with pytest.raises(_lib.EngineError):
+        d.read(pos_out, 1)                                           # nothing beyond the last good member
+    d.release()
+    s = api.make_full_decompression_stream("gzip", bytes(bad))
+    got = b""
+    with pytest.raises(api.DecompressionError):
+        while True:
+            chunk = s.read(7777)
+            if not chunk:
+                break
+            got += chunk
+    assert got == b"".join(parts[:4])
+    # two streams alive at once do not disturb each other (handles, not a per-context singleton)
+    s1 = api.make_full_decompression_stream("gzip", b"".join(members[:3]))
+    s2 = api.make_full_decompression_stream("gzip", b"".join(members[3:]))
+    a = s1.read(100); b = s2.read(100)
+    assert a + s1.read() == b"".join(parts[:3]) and b + s2.read() == b"".join(parts[3:])
+
+
+def test_decode_stream_into_caller_buffer():
+    import ctypes
+    import gzip
+    from decompress_amd import _lib
+    parts = [corpus.mixed(50000, seed=80 + i) for i in range(5)]
+    data = b"".join(gzip.compress(p, 6) for p in parts)
+    want = b"".join(parts)
+    eng = api._get_engine()
+    buf = ctypes.create_string_buffer(len(want) + 100)
+    rc, n, res, info = eng.decode_stream_into(_lib.FMT_GZIP, data, buf, True)
+    assert (rc, n, res.status, info.nmembers) == (0, len(want), 0, 5) and buf.raw[:n] == want
+    assert buf.raw[n:] == b"\0" * 100                                # nothing written beyond the stream
+    small = ctypes.create_string_buffer(len(want) - 1)
+    rc, n, res, _ = eng.decode_stream_into(_lib.FMT_GZIP, data, small, True)
+    assert (rc, n, res.status) == (1, len(want), 0) and small.raw == b"\0" * (len(want) - 1)
