@@ -827,7 +827,19 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 const uint32_t len = (tx >> 2) & 0x3FFF;
                 const uint32_t p = (uint32_t)(pos0 + (tx >> 16)) + shift;     // ring index of the destination
                 const uint32_t src = p - dist;
-                if (dist >= len) {
+                const int64_t sabs0 = (int64_t)(pos0 + (tx >> 16)) - (int64_t)dist;
+                if (sabs0 < 0) {
+                    // the source starts in the preset history and runs on into this round's output: byte k repeats
+                    // byte k mod dist of the window [sabs0, sabs0 + dist), which is final (history, or the ring)
+                    for (uint32_t k0 = 0; k0 < len; k0 = uni(k0 + 64)) {
+                        const uint32_t k = k0 + lane;
+                        const int64_t s = sabs0 + (int64_t)(k % dist);
+                        const uint32_t v = s < 0 ? (uint32_t)prefix_end[k < len ? s : -1]
+                                                 : (uint32_t)L.ring[(uint32_t)((uint64_t)s + shift) & RING_MASK];
+                        if (k < len) L.ring[(p + k) & RING_MASK] = (uint8_t)v;
+                    }
+                    join_lanes();
+                } else if (dist >= len) {
                     for (uint32_t k0 = 0; k0 < len; k0 = uni(k0 + 64)) {
                         const uint32_t k = k0 + lane;
                         const uint32_t v = L.ring[(src + k) & RING_MASK];

@@ -34,7 +34,8 @@ def check_xz(engine, data, expect=None):
             assert got == expect
     else:
         bad = [r for r in res if r.status != 0]
-        assert bad and bad[0].status == er.status, ([r.status for r in res], er.status)
+        assert bad and (bad[0].status, bad[0].detail) == (er.status, er.detail), \
+            ([(r.status, r.detail) for r in res], er.status, er.detail)
     return res
 
 
@@ -68,6 +69,30 @@ def test_one_mib_blocks(engine):
     data = xzutil.xz_cli(d, "--block-size=1MiB", "--lzma2=preset=6", "--check=crc64")
     res = check_xz(engine, data, d)
     assert len(res) == 3 and all(r.out_len == 1 << 20 for r in res)
+
+
+def test_config4_shape_one_mib_blocks_x86_sha256(engine):
+    """BASELINE configs[3] as stated: 1 MiB LZMA2 blocks behind the x86 BCJ filter with SHA-256 (and CRC64) checks,
+    every block's check verified on the device; also through the stream entry point (index, footer)."""
+    d = corpus.x86ish(4 * (1 << 20) + 12345, seed=31)
+    for chk, clen in (("sha256", 32), ("crc64", 8)):
+        data = xzutil.xz_cli(d, "--block-size=1MiB", "--x86", "--lzma2=preset=6", f"--check={chk}")
+        res = check_xz(engine, data, d)
+        assert len(res) == 5 and all(r.out_len == 1 << 20 for r in res[:4]) and all(r.check_len == clen for r in res)
+        if chk == "sha256":
+            import hashlib
+            for k, r in enumerate(res):
+                assert bytes(r.check[:32]) == hashlib.sha256(d[k << 20:(k + 1) << 20]).digest()
+        got, sres, info = engine.decode_stream(_lib.FMT_XZ, data, True)
+        assert sres.status == 0 and got == d and info.first_header[0] == (10 if chk == "sha256" else 4)
+        # a damaged block check is found on the device and reported with the stored value's first word
+        bad = bytearray(data)
+        units, _ = split(_lib.FMT_XZ, data)
+        pos = units[2].in_off - 16 - 1                 # last byte of block 1's check (block 2's header: 12 bytes + CRC-32)
+        bad[pos] ^= 0x80
+        got, sres, _ = engine.decode_stream(_lib.FMT_XZ, bytes(bad), True)
+        er, eo = oracle.decompress(8, bytes(bad), True, cap=len(d) + 16)
+        assert (sres.status, sres.detail) == (er.status, er.detail) and sres.status == 155 and got == d[:1 << 20]
 
 
 def test_reference_lol_vector(engine):
@@ -144,6 +169,8 @@ def test_corrupt_xz_blocks(engine):
         assert res[0].status == er.status, (t, res[0].status, er.status)
         if er.status == 0:
             assert out.raw[:res[0].out_len] == eo
+        else:
+            assert res[0].detail == er.detail, (t, res[0].status, res[0].detail, er.detail)
 
 
 @pytest.mark.parametrize("name", ["powerpc", "ia64", "arm", "armthumb", "sparc"])
