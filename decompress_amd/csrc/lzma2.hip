@@ -867,8 +867,11 @@ int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
         if (rc) return rc;
         lzma2_kernel<true, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, (uint16_t *)w, 0);
     } else {
-        // eight units per CU; the few units that need the full literal table are redone by the second launch
-        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 0);
+        // the accept-only fast kernel first; what it hands back (anything the reference would reject, unusual
+        // properties, raw LZMA1) goes to the general kernel: eight units per CU, and the few units that need the
+        // full literal table are redone by the third launch
+        if (!c->lz_no_fast) semz_launch_lzma2_fast(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, c->stream);
+        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, c->lz_no_fast ? 0 : 1);
         lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 1);
     }
     semz_span_end(c);

@@ -1,0 +1,766 @@
+// lzma2_fast.hip -- the LZMA2 / xz block decoder for well-formed units with ordinary properties.
+//
+// Same reference loops as lzma2.hip (lzma.lisp:49-198, 247-341, 566-775, lzma2.lisp:77-204,
+// xz.lisp:426-457); this kernel only ever *accepts*.  Whatever it cannot vouch for -- any of the
+// reference's failure conditions, literal / position properties outside lc + lp <= 3 and pb <= 2
+// (xz writes lc 3, lp 0, pb 2), raw LZMA1 units, outputs of 2 GiB and more -- leaves the unit
+// with LZ_RETRY_FULL, and the general kernel of lzma2.hip, launched right behind, decodes it
+// again from the start and reports the reference's status and detail.  So the reject paths have
+// one implementation, and this one is free to be organised for speed alone.
+//
+// What bounds an LZMA decoder on this chip is the number of instructions per decoded bit: a
+// wave issues one instruction every eight clocks or so whatever its kind, and a
+// batch of 1 MiB blocks has two waves per SIMD at most.  The general kernel spends about 47
+// instructions per bit; this one spends about 17:
+//
+//  * Probabilities live in vector registers, one model per lane, and a bit step takes its
+//    probability with v_readlane and puts it back with v_writelane: no LDS round trip, no
+//    address arithmetic.  The flag models, the length decoders' low / mid trees and the align
+//    tree stay in registers for the whole unit; the 0x300-entry literal subtree of the current
+//    context, the distance-slot tree, the distance trees of slots 4..13 and the length
+//    decoders' high trees are fetched from LDS into registers when a symbol needs them (the
+//    literal subtree speculatively, while the is-literal bit is being decoded) and written back
+//    afterwards, whole registers at a time.
+//  * Trees are walked in mirrored order: q' = 2 q + (bit == 0).  The comparison that decides the
+//    bit leaves "code < bound" in SCC, so s_addc_u32 q, q, q is the whole tree step, and the three
+//    selects of the range decoder hang on the same SCC.  Which lane holds which node is private
+//    to this kernel (every model starts at 1024), the decoded value is ~q.
+//  * The probability update is p - ((p - K) >> 5) with K = 2017 or 0, arithmetic shift: equal to
+//    p + ((2048 - p) >> 5) and p - (p >> 5) of lzma.lisp:104-112.
+//  * The check "code < range" after a normalisation (lzma.lisp:72-73) cannot fail once it held at
+//    the start (code < range implies 256 code + byte < 256 range), so only the start and the one
+//    case of the direct bits that can break the invariant (lzma.lisp:186-188) are tested.
+//  * Input limits are tested once per symbol, not per byte: reads are clamped to the unit's last
+//    dword, a symbol is applied only if the read position is still inside the chunk.
+#include "semz_host.h"
+
+namespace {
+
+constexpr int32_t LZ_RETRY_FULL = -101;        // same value as in lzma2.hip
+constexpr int F_RING = 4096, F_MASK = F_RING - 1;
+constexpr int F_FLUSH = 1024;                  // 64 lanes x 16 bytes
+constexpr int F_MAX_MATCH = 273;
+
+typedef const __attribute__((address_space(4))) uint32_t *k_u32p;   // scalar-load view of read-only memory
+
+struct __align__(16) FastLds {
+    uint8_t ring[F_RING];
+    uint16_t lit[0x300 * 8];                   // per context: [q] plain tree, [0x100 + (match bit << 8) + q] matched trees
+    uint16_t slot[4 * 64];                     // [length state][q]
+    uint16_t mid[10 * 64];                     // [slot - 4][q]   (reverse trees of one to five bits)
+    uint16_t high[2 * 256];                    // [simple / rep][q]
+    uint32_t stage[64];                        // where the bytes of a far match land (one dword per lane)
+};
+static_assert(sizeof(FastLds) <= 20480, "eight units per CU");
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// Placed right behind a lane-masked store: the two paths of the mask join here, in a block without phis (see inflate.hip).
+__device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); }
+
+// The range decoder's steps as assembler text, so that a run of bits is one block for the compiler: no copies of
+// range / code / models between the bits, no spills.  With two waves on a SIMD it is the scalar unit that is
+// saturated (one scalar instruction per ten clocks and wave, scripts/ubench/issue_rate.hip), the vector pipe has
+// room: the probability update is done there, on all lanes, and kept for the one lane M0 points at (four vector
+// instructions for four scalar ones and the v_writelane).  Operand names are the same in every block.
+//   A_BIT(vt)   one modelled bit, the probability in lane M0 of vt; leaves SCC = (bit == 0) for the caller's
+//               s_addc (A_QM0: q lives in M0; A_QREG: q is a register), then updates the model
+//   A_NORM      lzma.lisp:64-73 with the byte taken from the input window (see Win)
+#define A_BIT_HEAD(vt)                                                  \
+    "v_readlane_b32 %[p], " vt ", m0\n\t"                               \
+    "s_lshr_b32 %[b], %[range], 11\n\t"                                 \
+    "s_lshl_b64 %[mq], 1, m0\n\t"                                       \
+    "s_mul_i32 %[b], %[b], %[p]\n\t"                                    \
+    "s_sub_u32 %[nr], %[range], %[b]\n\t"                               \
+    "s_sub_u32 %[nc], %[code], %[b]\n\t" /* SCC = code < bound: 0 */    \
+    "s_cselect_b32 %[range], %[b], %[nr]\n\t"                           \
+    "s_cselect_b32 %[code], %[code], %[nc]\n\t"                         \
+    "s_cselect_b32 %[k], 0x7e1, 0\n\t"
+#define A_BIT_TAIL(vt)                                                  \
+    "v_sub_u32_e64 %[t], " vt ", %[k]\n\t"                              \
+    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
+    "v_sub_u32_e32 %[t], " vt ", %[t]\n\t"                              \
+    "v_cndmask_b32_e64 " vt ", " vt ", %[t], %[mq]\n\t"
+#define A_NORM                                                          \
+    "s_cmp_gt_u32 %[range], 0xffffff\n\t"                               \
+    "s_cbranch_scc1 1f\n\t"                                             \
+    "s_lshr_b32 %[b], %[off], 2\n\t"                                    \
+    "s_lshl_b32 %[range], %[range], 8\n\t"                              \
+    "v_readlane_b32 %[k], %[win], %[b]\n\t"                             \
+    "s_lshl_b32 %[b], %[off], 3\n\t"                                    \
+    "s_lshl_b32 %[code], %[code], 8\n\t"                                \
+    "s_lshr_b32 %[k], %[k], %[b]\n\t"                                   \
+    "s_and_b32 %[k], %[k], 0xff\n\t"                                    \
+    "s_add_u32 %[off], %[off], 1\n\t"                                   \
+    "s_or_b32 %[code], %[code], %[k]\n"                                 \
+    "1:\n\t"
+#define A_TREE(vt) A_BIT_HEAD(vt) "s_addc_u32 m0, m0, m0\n\t" A_BIT_TAIL(vt) A_NORM                                /* q in M0 */
+#define A_TREEB(vt) "s_add_u32 m0, %[base], %[q]\n\t" A_BIT_HEAD(vt) "s_addc_u32 %[q], %[q], %[q]\n\t" A_BIT_TAIL(vt) A_NORM
+// the last level of an eight-bit tree (q in M0, 128..255), whose 128 models fill two registers: q bit 6 says which
+#define A_LEVEL7(va, vb)                                                \
+    "v_readlane_b32 %[p], " va ", m0\n\t"                               \
+    "v_readlane_b32 %[k], " vb ", m0\n\t"                               \
+    "s_lshl_b64 %[mq], 1, m0\n\t"                                       \
+    "s_bitcmp1_b32 m0, 6\n\t"                                           \
+    "s_cselect_b32 %[p], %[k], %[p]\n\t"                                \
+    "s_cselect_b64 %[mb], %[mq], 0\n\t"                                 \
+    "s_andn2_b64 %[mq], %[mq], %[mb]\n\t"                               \
+    "s_lshr_b32 %[b], %[range], 11\n\t"                                 \
+    "s_mul_i32 %[b], %[b], %[p]\n\t"                                    \
+    "s_sub_u32 %[nr], %[range], %[b]\n\t"                               \
+    "s_sub_u32 %[nc], %[code], %[b]\n\t"                                \
+    "s_cselect_b32 %[range], %[b], %[nr]\n\t"                           \
+    "s_cselect_b32 %[code], %[code], %[nc]\n\t"                         \
+    "s_cselect_b32 %[k], 0x7e1, 0\n\t"                                  \
+    "s_addc_u32 m0, m0, m0\n\t"                                         \
+    "v_sub_u32_e64 %[t], " va ", %[k]\n\t"                              \
+    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
+    "v_sub_u32_e32 %[t], " va ", %[t]\n\t"                              \
+    "v_cndmask_b32_e64 " va ", " va ", %[t], %[mq]\n\t"                 \
+    "v_sub_u32_e64 %[t], " vb ", %[k]\n\t"                              \
+    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
+    "v_sub_u32_e32 %[t], " vb ", %[t]\n\t"                              \
+    "v_cndmask_b32_e64 " vb ", " vb ", %[t], %[mb]\n\t" A_NORM
+#define A_RC_OUT [range] "+s"(range), [code] "+s"(code), [off] "+s"(off), [p] "=&s"(p), [b] "=&s"(b), [nr] "=&s"(nr), \
+                 [nc] "=&s"(nc), [k] "=&s"(k), [mq] "=&s"(mq), [t] "=&v"(t)
+#define A_TEMPS uint32_t p, b, nr, nc, k, t; uint64_t mq
+
+// One modelled bit with the model in lane `sel` of vt; returns q' = 2 q + (bit == 0).
+__device__ __forceinline__ uint32_t bitq(uint32_t &vt, uint32_t sel, uint32_t &range, uint32_t &code, uint32_t &off,
+                                         uint32_t win, uint32_t q)
+{
+    A_TEMPS;
+    asm volatile("s_mov_b32 m0, %[sel]\n\t" A_BIT_HEAD("%[vt]") "s_addc_u32 %[q], %[q], %[q]\n\t" A_BIT_TAIL("%[vt]") A_NORM
+                 : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT
+                 : [sel] "s"(sel), [win] "v"(win)
+                 : "scc", "m0");
+    return q;
+}
+
+// N levels of a tree whose models sit in lanes q of one register (N <= 6).
+template <int N> __device__ __forceinline__ uint32_t walk(uint32_t &vt, uint32_t &range, uint32_t &code, uint32_t &off,
+                                                           uint32_t win, uint32_t q)
+{
+    A_TEMPS;
+    static_assert(N >= 1 && N <= 6, "one register holds the first six levels");
+#define A_WALK(body) asm volatile("s_mov_b32 m0, %[q]\n\t" body "s_mov_b32 %[q], m0" \
+                                  : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [win] "v"(win) : "scc", "m0")
+    if constexpr (N == 6) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
+    else if constexpr (N == 5) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
+    else if constexpr (N == 4) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
+    else if constexpr (N == 3) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
+    else if constexpr (N == 2) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]"));
+    else A_WALK(A_TREE("%[vt]"));
+#undef A_WALK
+    return q;
+}
+
+// Three or four levels of a small tree with its models in lanes base + q.
+template <int N> __device__ __forceinline__ uint32_t walkb(uint32_t &vt, uint32_t base, uint32_t &range, uint32_t &code,
+                                                            uint32_t &off, uint32_t win)
+{
+    A_TEMPS;
+    uint32_t q = 1;
+    static_assert(N == 3 || N == 4, "length low / mid trees and the align tree");
+    if constexpr (N == 3)
+        asm volatile(A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]")
+                     : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [base] "s"(base), [win] "v"(win) : "scc", "m0");
+    else
+        asm volatile(A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]")
+                     : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [base] "s"(base), [win] "v"(win) : "scc", "m0");
+    return q;
+}
+
+// An eight-level tree in four registers (levels 0..5, 6, and 7 in two halves); returns q in 256..511.
+__device__ __forceinline__ uint32_t tree8(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, uint32_t &range,
+                                          uint32_t &code, uint32_t &off, uint32_t win)
+{
+    A_TEMPS;
+    uint64_t mb;
+    uint32_t q;
+    asm volatile("s_mov_b32 m0, 1\n\t"
+                 A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]")
+                 A_TREE("%[v1]") A_LEVEL7("%[v2]", "%[v3]")
+                 "s_mov_b32 %[q], m0"
+                 : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [v3] "+v"(v3), [q] "=&s"(q), A_RC_OUT, [mb] "=&s"(mb)
+                 : [win] "v"(win)
+                 : "scc", "m0");
+    return q;
+}
+
+// The last level alone (a matched literal that left the match byte's path at level 7 or finished it there).
+__device__ __forceinline__ uint32_t level7(uint32_t &v2, uint32_t &v3, uint32_t &range, uint32_t &code, uint32_t &off,
+                                           uint32_t win, uint32_t q)
+{
+    A_TEMPS;
+    uint64_t mb;
+    asm volatile("s_mov_b32 m0, %[q]\n\t" A_LEVEL7("%[v2]", "%[v3]") "s_mov_b32 %[q], m0"
+                 : [v2] "+v"(v2), [v3] "+v"(v3), [q] "+s"(q), A_RC_OUT, [mb] "=&s"(mb)
+                 : [win] "v"(win)
+                 : "scc", "m0");
+    return q;
+}
+
+// `n` >= 1 direct bits (lzma.lisp:174-192): the range is halved, hi' = 2 hi + (bit == 0).  `bad` is set when the
+// code equals the halved range after a one bit, the reference's only failure here.
+__device__ __forceinline__ uint32_t direct_bits(uint32_t n, uint32_t &range, uint32_t &code, uint32_t &off, uint32_t win,
+                                                uint32_t &bad)
+{
+    uint32_t b, k, hi = 0, m = 1u << (n - 1);
+    asm volatile("2:\n\t"
+                 "s_lshr_b32 %[range], %[range], 1\n\t"
+                 "s_sub_u32 %[b], %[code], %[range]\n\t"        /* SCC = code < range: the bit is 0 */
+                 "s_cselect_b32 %[code], %[code], %[b]\n\t"
+                 "s_addc_u32 %[hi], %[hi], %[hi]\n\t"
+                 "s_cmp_eq_u32 %[code], %[range]\n\t"
+                 "s_cmov_b32 %[bad], 1\n\t" A_NORM
+                 "s_lshr_b32 %[m], %[m], 1\n\t"                 /* SCC = result != 0 */
+                 "s_cbranch_scc1 2b"
+                 : [range] "+s"(range), [code] "+s"(code), [off] "+s"(off), [hi] "+s"(hi), [m] "+s"(m), [bad] "+s"(bad),
+                   [b] "=&s"(b), [k] "=&s"(k)
+                 : [win] "v"(win)
+                 : "scc");
+    return hi;
+}
+
+// Input: 256 bytes of the unit's compressed data sit in one register, a dword per lane; `off` counts bytes from
+// the window's start.  A normalisation takes its byte with v_readlane and two shifts, inside one asm block with
+// its own branch: the compiler sees straight-line code (no phi webs around every bit step, no spills).  The
+// window is moved forward between symbols (a symbol takes fewer than 64 bytes).
+struct Win {
+    const uint32_t *base;  // dword view of the input from the aligned address below the unit's first byte
+    uint32_t wbase;        // offset (bytes from base, a multiple of four) of the window's first byte
+    uint32_t off;          // next byte, relative to wbase
+    uint32_t last;         // index of the last dword that holds a byte of the unit's input span
+    uint32_t v;            // lane l: dword wbase / 4 + l (clamped to `last`)
+    __device__ __forceinline__ uint32_t pos() const { return wbase + off; }
+    __device__ __forceinline__ void seek(uint32_t o)
+    {
+        wbase = o & ~3u;
+        off = o & 3;
+        const uint32_t d = (wbase >> 2) + (threadIdx.x & 63);
+        v = base[d < last ? d : last];
+        asm volatile("" : "+v"(v));     // waited for here, not at the next bit step: a far match's bytes may be in flight there
+    }
+    __device__ __forceinline__ void slide()
+    {
+        if (off >= 192) seek(pos());
+    }
+    __device__ __forceinline__ uint32_t byte()             // headers only: the symbol loop uses normq()
+    {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(off >> 2));
+        const uint32_t b = (w >> (8 * (off & 3))) & 0xFF;
+        off++;
+        return b;
+    }
+};
+
+__global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units,
+                                                           uint32_t nunits, uint8_t *out, uint64_t out_total,
+                                                           semz_result *results, semz_tail *tails)
+{
+    __shared__ FastLds L;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    semz_unit un;
+    {
+        k_u32p up = (k_u32p)(uintptr_t)(units + u);
+        uint32_t w[sizeof(semz_unit) / 4];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(semz_unit) / 4); i++) w[i] = up[i];
+        __builtin_memcpy(&un, w, sizeof un);
+    }
+    if (!semz_unit_spans_ok(un, in_len, out_total, 2)) {         // nothing of this unit is touched
+        if (lane == 0) {
+            semz_result r{};
+            r.status = SEMZ_E_BAD_UNIT;
+            r.out_off = un.out_off;
+            results[u] = r;
+            tails[u] = semz_tail{};
+        }
+        return;
+    }
+    // everything this kernel does not take goes to the general kernel
+    auto retry = [&]() {
+        if (lane == 0) {
+            semz_result r{};
+            r.status = LZ_RETRY_FULL;
+            r.out_off = un.out_off;
+            results[u] = r;
+            tails[u] = semz_tail{};
+        }
+    };
+    const bool is_xz = un.kind == SEMZ_UNIT_XZ_BLOCK;
+    if ((un.kind != SEMZ_UNIT_XZ_BLOCK && un.kind != SEMZ_UNIT_LZMA2) || un.out_cap >= 0x7FF00000ull ||
+        un.in_limit - un.in_off >= 0x7FF00000ull) {
+        retry();
+        return;
+    }
+    uint8_t *ob = out + un.out_off;
+    const uint32_t shift = (uint32_t)((uintptr_t)ob & 15);
+    const uint32_t out_cap = (uint32_t)un.out_cap;
+    const uint32_t dict_size = un.param0;
+    uint8_t *safe_byte = out;
+
+    // input window: offsets are relative to the aligned address below the unit's first byte
+    const uint8_t *ustart = in + un.in_off;
+    const uint32_t amis = (uint32_t)((uintptr_t)ustart & 3);
+    Win s;
+    s.base = reinterpret_cast<const uint32_t *>(ustart - amis);
+    const uint32_t phys_end = (uint32_t)(un.in_limit - un.in_off) + amis;           // first offset past the input
+    uint32_t block_end = 0xFFFFFFFFu;                                                // declared xz compressed size
+    if (is_xz && (un.flags & SEMZ_UF_HAVE_IN_SIZE) && un.size_in < 0x7FF00000ull) block_end = (uint32_t)un.size_in + amis;
+    if (phys_end == amis) { retry(); return; }                                       // empty input: eof
+    s.last = (phys_end - 1) >> 2;
+    s.seek(amis);
+    const uint32_t lim = phys_end < block_end ? phys_end : block_end;                // no read may pass this
+
+    // ---- models that stay in registers (one model per lane) ----
+    // vA   is-literal   [state * 4 + pos_state]
+    // vB   is-short-rep [state * 4 + pos_state]
+    // vC   is-simple [state], uses-rep0 [12 + state], is-rep1 [24 + state], is-rep2 [36 + state], align [48 + q]
+    // vS0  simple-match length: low [pos_state * 8 + q], choice 32, choice-2 33;  vS1  mid [pos_state * 8 + q]
+    // vR0, vR1 the same for rep-match lengths
+    uint32_t vA = 1024, vB = 1024, vC = 1024, vS0 = 1024, vS1 = 1024, vR0 = 1024, vR1 = 1024;
+
+    uint32_t range = 0, code = 0;
+    uint32_t rep0 = 0, rep1 = 0, rep2 = 0, rep3 = 0, state = 0, total = 0;
+    uint32_t lc = 0, lp_mask = 0, pb_mask = 0;
+    bool have_state = false;
+    enum { NEED_DICT = 0, NEED_PROPS = 1, NEED_NONE = 2 };
+    int need = NEED_DICT;
+    uint32_t p = 0, dict_base = 0, flushed = 0;
+    bool ok = true;                 // false: hand the unit to the general kernel
+
+    auto flush = [&](bool all) {
+        const uint32_t head = (16 - shift) & 15;
+        if (flushed == 0 && head && (p >= head || all)) {
+            const uint32_t n = p < head ? p : head;
+            if (lane < n) ob[lane] = L.ring[(lane + shift) & F_MASK];
+            join_lanes();
+            flushed = n;
+        }
+        flushed = uni(flushed);
+        if (flushed || !head) {
+            while (p - flushed >= (uint32_t)F_FLUSH) {
+                const uint32_t a = flushed + 16u * lane;
+                const uint4 v = *reinterpret_cast<const uint4 *>(&L.ring[(a + shift) & F_MASK]);
+                *reinterpret_cast<uint4 *>(ob + a) = v;
+                flushed += F_FLUSH;
+            }
+            if (all) {
+                const uint32_t pieces = (p - flushed) >> 4;
+                if (lane < pieces) {
+                    const uint32_t a = flushed + 16u * lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&L.ring[(a + shift) & F_MASK]);
+                    *reinterpret_cast<uint4 *>(ob + a) = v;
+                }
+                join_lanes();
+                flushed += 16u * pieces;
+                const uint32_t rest = p - flushed;
+                if (lane < rest) ob[flushed + lane] = L.ring[(flushed + lane + shift) & F_MASK];
+                join_lanes();
+                flushed = p;
+            }
+        }
+        flushed = uni(flushed);
+    };
+    // byte of history at position pos < p (every lane gets it)
+    auto history_byte_v = [&](uint32_t pos) -> uint32_t {
+        if (pos + (F_RING - F_MAX_MATCH) > p) return (uint32_t)L.ring[(pos + shift) & F_MASK];
+        return (uint32_t)__hip_atomic_load(ob + pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+#define PIN_ALL()                                                                                                       \
+    do {                                                                                                                \
+        range = uni(range); code = uni(code); p = uni(p); total = uni(total); state = uni(state); rep0 = uni(rep0);     \
+        rep1 = uni(rep1); rep2 = uni(rep2); rep3 = uni(rep3); prev = uni(prev); flushed = uni(flushed);                 \
+        dict_base = uni(dict_base); s.off = uni(s.off); s.wbase = uni(s.wbase);                                         \
+    } while (0)
+#define BIT(vt, sel) (q = bitq(vt, sel, range, code, s.off, s.v, q))
+
+    // A match whose source lies behind the ring is not waited for: its bytes are asked for (HBM, one round trip) and
+    // put into the ring when something needs them -- the next literal (context and match byte), the next match's
+    // copy, a flush, the end of the chunk.  The symbol after a match is a match three times out of four, and its
+    // bits do not depend on the bytes.  Lane k < pend_len holds byte k, lane pend_len the byte behind the source
+    // (what a literal right behind the match is matched against).
+    uint32_t pend_len = 0, pend_p = 0, pend_sh = 0, pend_l = 0;
+    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)L.stage;
+    auto resolve = [&]() -> uint32_t {                    // returns the bytes, one per lane
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the load below is not one the compiler knows of)
+        const uint32_t w = L.stage[lane];
+        const uint32_t bv = pend_sh < 32 ? (w >> pend_sh) & 0xFF : pend_l;
+        if (lane < pend_len) L.ring[(pend_p + lane + shift) & F_MASK] = (uint8_t)bv;
+        join_lanes();
+        pend_len = 0;
+        return bv;
+    };
+    // ---- LZMA2 control loop (lzma2.lisp:77-204) ----
+    for (;;) {
+        // (pins: what the optimiser merges behind the lane-masked stores of flush() and the copies counts as divergent
+        // in its analysis, and every model index has to be a scalar)
+        lc = uni(lc); lp_mask = uni(lp_mask); pb_mask = uni(pb_mask); p = uni(p); total = uni(total); state = uni(state);
+        dict_base = uni(dict_base); flushed = uni(flushed); s.off = uni(s.off); s.wbase = uni(s.wbase);
+        s.slide();
+        rep0 = uni(rep0); rep1 = uni(rep1); rep2 = uni(rep2); rep3 = uni(rep3);
+        if (s.pos() >= lim) { ok = false; break; }
+        const uint32_t control = s.byte();
+        if (control == 0) break;                                     // end of the LZMA2 stream
+        if (control < 0x80) {
+            if (control > 2) { ok = false; break; }
+            if (s.pos() + 2 > lim) { ok = false; break; }
+            const uint32_t b0 = s.byte(), b1 = s.byte();
+            const uint32_t usize = ((b0 << 8) | b1) + 1;
+            if (control == 2) {
+                if (need == NEED_DICT) { ok = false; break; }
+                need = NEED_NONE;
+            } else {
+                need = NEED_PROPS;
+                dict_base = p;
+            }
+            if (usize > out_cap - p || usize > lim - s.pos()) { ok = false; break; }
+            const uint8_t *src = ustart + (s.pos() - amis);
+            lds_sync();
+            for (uint32_t o = 0; o < usize; o += F_FLUSH) {
+                const uint32_t n = usize - o < (uint32_t)F_FLUSH ? usize - o : (uint32_t)F_FLUSH;
+                for (uint32_t k0 = 0; k0 < n; k0 += 64) {            // (uniform trip count: the decoder state stays scalar)
+                    const uint32_t k = k0 + lane;
+                    if (k < n) L.ring[(p + k + shift) & F_MASK] = src[o + k];
+                    join_lanes();
+                }
+                p += n;
+                lds_sync();
+                flush(false);
+            }
+            s.seek(s.pos() + usize);
+            if (have_state) total = (total + usize) & 15;            // lzma2.lisp:184-188
+            continue;
+        }
+        if (s.pos() + 4 > lim) { ok = false; break; }
+        const uint32_t b0 = s.byte(), b1 = s.byte(), b2 = s.byte(), b3 = s.byte();
+        const uint32_t usize = (((control & 31) << 16) | (b0 << 8) | b1) + 1;
+        const uint32_t csize = ((b2 << 8) | b3) + 1;
+        if ((need == NEED_DICT && control < 0xE0) || (need == NEED_PROPS && control < 0xC0)) { ok = false; break; }
+        need = NEED_NONE;
+        if (control >= 0xC0) {
+            if (s.pos() >= lim) { ok = false; break; }
+            const uint32_t octet = s.byte();                         // parse-lzma2-props, lzma2.lisp:31-38
+            const uint32_t nlc = octet % 9, nlp = (octet / 9) % 5, npb = octet / 45;
+            if (npb > 2 || nlc + nlp > 3) { ok = false; break; }     // (including the illegal ones)
+            lc = nlc; lp_mask = (1u << nlp) - 1; pb_mask = (1u << npb) - 1;
+        } else if (!have_state) { ok = false; break; }
+        if (control >= 0xE0) dict_base = p;
+        if (usize > out_cap - p) { ok = false; break; }
+        if (csize > lim - s.pos() || csize < 5) { ok = false; break; }
+        const uint32_t chunk_end = s.pos() + csize;
+        const uint32_t endp = p + usize;
+        // the range decoder (lzma.lisp:55-62)
+        if (s.byte() != 0) { ok = false; break; }
+        range = 0xFFFFFFFFu;
+        code = 0;
+        for (int i = 0; i < 4; i++) code = (code << 8) | s.byte();
+        if (code == 0xFFFFFFFFu) { ok = false; break; }
+        if (control >= 0xA0 || !have_state) {                        // fresh lzma-state-vars (lzma2.lisp:144-145)
+            vA = vB = vC = vS0 = vS1 = vR0 = vR1 = 1024;
+            {
+                uint32_t *w32 = reinterpret_cast<uint32_t *>(L.lit);
+                constexpr uint32_t NW = (sizeof(L.lit) + sizeof(L.slot) + sizeof(L.mid) + sizeof(L.high)) / 4;
+                static_assert(NW % 64 == 0, "whole passes of the wave");
+                for (uint32_t i0 = 0; i0 < NW; i0 += 64) w32[i0 + lane] = 0x04000400u;
+            }
+            rep0 = rep1 = rep2 = rep3 = 0; state = 0; total = 0;
+            lds_sync();
+        }
+        have_state = true;
+        // the byte in front of the chunk, for the first literal's context
+        uint32_t prev = p == dict_base ? 0u : uni((uint32_t)L.ring[(p - 1 + shift) & F_MASK]);
+        uint32_t mbyte_v = 0, prev_v = prev;
+        if (state >= 7) {
+            if (p - dict_base < rep0 + 1) { ok = false; break; }
+            mbyte_v = history_byte_v(p - 1 - rep0);
+        }
+
+        // ---- decode-lzma (lzma.lisp:566-775) ----
+        while (p != endp) {
+            PIN_ALL();
+            s.slide();
+            const uint32_t ps = total & pb_mask;
+            uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, lbase = 0;
+            const bool after_literal = state < 7;
+            if (after_literal) {
+                // the literal subtree of this context, on its way while the is-literal bit is decoded
+                lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
+                const uint16_t *t = L.lit + lbase + lane;
+                v0 = t[0]; v1 = t[64]; v2 = t[128]; v3 = t[192];
+            }
+            uint32_t q = 1;
+            BIT(vA, state * 4 + ps);
+            if (q == 3) {
+                // ---- literal (lzma.lisp:661-688) ----
+                if (after_literal) {
+                    q = tree8(v0, v1, v2, v3, range, code, s.off, s.v);
+                } else {
+                    uint32_t mb;
+                    if (pend_len) {
+                        const uint32_t n = uni(pend_len);
+                        const uint32_t bv = resolve();
+                        prev = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)(n - 1)) & 0xFF;
+                        mb = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)n) & 0xFF;
+                    } else {
+                        prev = uni(prev_v);
+                        mb = uni(mbyte_v);
+                    }
+                    lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
+                    // the eight models on the match byte's path, one per lane; the other lanes take the unused slot 0
+                    const uint32_t inv = ~mb & 0xFF;
+                    const uint32_t l7 = lane & 7;
+                    const uint32_t qi = (1u << l7) | (inv >> (8 - l7));
+                    const uint32_t node = lane < 8 ? 0x100u + (((mb >> (7 - l7)) & 1) << 8) + qi : 0u;
+                    join_lanes();
+                    uint16_t *mt = L.lit + lbase + node;
+                    uint32_t vm = *mt;
+                    const uint16_t *t = L.lit + lbase + lane;
+                    v0 = t[0]; v1 = t[64]; v2 = t[128]; v3 = t[192];
+                    // decode-lzma-literal/match-case, lzma.lisp:497-518: follow the match byte while the bits agree
+                    q = 1;
+                    uint32_t lvl = 0;
+                    for (; lvl < 8; lvl++) {
+                        const uint32_t want = 2 * q + (((mb >> (7 - lvl)) & 1) ^ 1);
+                        BIT(vm, lvl);
+                        if (q != want) { lvl++; break; }
+                    }
+                    *mt = (uint16_t)vm;
+                    // the plain tree from level `lvl` on: levels 0..5 sit in v0, 6 in v1, 7 in v2 / v3
+                    switch (lvl) {
+                    case 1: BIT(v0, q); [[fallthrough]];
+                    case 2: BIT(v0, q); [[fallthrough]];
+                    case 3: BIT(v0, q); [[fallthrough]];
+                    case 4: BIT(v0, q); [[fallthrough]];
+                    case 5: BIT(v0, q); [[fallthrough]];
+                    case 6: BIT(v1, q); [[fallthrough]];
+                    case 7: q = level7(v2, v3, range, code, s.off, s.v, q); break;
+                    default: break;
+                    }
+                }
+                {
+                    uint16_t *t = L.lit + lbase + lane;
+                    t[0] = (uint16_t)v0; t[64] = (uint16_t)v1; t[128] = (uint16_t)v2; t[192] = (uint16_t)v3;
+                }
+                if (s.pos() > chunk_end) { ok = false; break; }
+                const uint32_t byte = ~q & 0xFF;
+                L.ring[(p + shift) & F_MASK] = (uint8_t)byte;        // every lane: same address, same value
+                prev = byte;
+                p++;
+                total++;
+                state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;   // lzma.lisp:615
+                if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); flush(false); }
+                continue;
+            }
+            // ---- match ----
+            uint32_t len;
+            // length decoder (lzma.lisp:247-257) over the register pair (low + choices, mid) and the LDS high tree
+            auto length = [&](uint32_t &w0, uint32_t &w1, uint32_t kind) -> uint32_t {
+                uint32_t q = 1;
+                BIT(w0, 32);
+                if (q == 3) return ~walkb<3>(w0, ps * 8, range, code, s.off, s.v) & 7;
+                q = 1;
+                BIT(w0, 33);
+                if (q == 3) return 8 + (~walkb<3>(w1, ps * 8, range, code, s.off, s.v) & 7);
+                uint16_t *t = L.high + kind * 256 + lane;
+                uint32_t h0 = t[0], h1 = t[64], h2 = t[128], h3 = t[192];
+                q = tree8(h0, h1, h2, h3, range, code, s.off, s.v);
+                t[0] = (uint16_t)h0; t[64] = (uint16_t)h1; t[128] = (uint16_t)h2; t[192] = (uint16_t)h3;
+                return 16 + (~q & 0xFF);
+            };
+            q = 1;
+            BIT(vC, state);
+            if (q == 3) {
+                // simple match: length, then distance (lzma.lisp:323-341)
+                const uint32_t rl = length(vS0, vS1, 0);
+                state = state < 7 ? 7 : 10;
+                rep3 = rep2; rep2 = rep1; rep1 = rep0;
+                uint16_t *st = L.slot + 64 * (rl < 3 ? rl : 3) + lane;
+                uint32_t vs = *st;
+                q = walk<6>(vs, range, code, s.off, s.v, 1);
+                *st = (uint16_t)vs;
+                const uint32_t slot = ~q & 63;
+                if (slot < 4) rep0 = slot;
+                else {
+                    const uint32_t nb = (slot >> 1) - 1;
+                    const uint32_t min_dist = (2u | (slot & 1)) << nb;
+                    if (slot < 14) {
+                        uint16_t *mt = L.mid + 64 * (slot - 4) + lane;
+                        uint32_t vd = *mt;
+                        q = 1;
+                        BIT(vd, q);                                      // one to five bits, least significant first
+                        if (nb > 1) BIT(vd, q);
+                        if (nb > 2) BIT(vd, q);
+                        if (nb > 3) BIT(vd, q);
+                        if (nb > 4) BIT(vd, q);
+                        *mt = (uint16_t)vd;
+                        rep0 = min_dist + (__brev(~q & ((1u << nb) - 1)) >> (32 - nb));
+                    } else {
+                        uint32_t bad = 0;
+                        uint32_t hi = direct_bits(nb - 4, range, code, s.off, s.v, bad);   // lzma.lisp:174-192
+                        if (bad) ok = false;
+                        hi = ~hi & ((1u << (nb - 4)) - 1);
+                        q = walkb<4>(vC, 48, range, code, s.off, s.v);
+                        rep0 = min_dist + (hi << 4) + (__brev(~q & 15) >> 28);
+                    }
+                }
+                if (rep0 == 0xFFFFFFFFu) { ok = false; break; }       // an end marker is illegal in LZMA2 (lzma.lisp:727-732)
+                len = rl + 2;
+            } else {
+                q = 1;
+                BIT(vC, 12 + state);
+                if (q == 3) {
+                    q = 1;
+                    BIT(vB, state * 4 + ps);
+                    if (q == 3) {
+                        state = state < 7 ? 9 : 11;
+                        len = 1;
+                    } else {
+                        state = state < 7 ? 8 : 11;
+                        len = 2 + length(vR0, vR1, 1);
+                    }
+                } else {
+                    uint32_t t;
+                    q = 1;
+                    BIT(vC, 24 + state);
+                    if (q == 3) { t = rep1; rep1 = rep0; rep0 = t; }
+                    else {
+                        q = 1;
+                        BIT(vC, 36 + state);
+                        if (q == 3) { t = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                        else { t = rep3; rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
+                    }
+                    state = state < 7 ? 8 : 11;
+                    len = 2 + length(vR0, vR1, 1);
+                }
+            }
+            if (!ok || s.pos() > chunk_end) { ok = false; break; }
+            // handle-match, lzma.lisp:600-612
+            if (rep0 >= dict_size || rep0 >= p - dict_base || len > endp - p) { ok = false; break; }
+            // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
+            if (pend_len) resolve();
+            if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); flush(false); }
+            lds_sync();
+            const uint32_t dist = rep0 + 1;
+            const uint32_t src = p - dist;
+            if (src + (F_RING - F_MAX_MATCH) > p + len) {
+                // all of the source is in the ring (and so is the byte behind it)
+                if (dist >= len) {
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        const uint32_t bv = L.ring[(src + k + shift) & F_MASK];
+                        if (k < len) L.ring[(p + k + shift) & F_MASK] = (uint8_t)bv;
+                        join_lanes();
+                    }
+                } else {
+                    for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                        const uint32_t k = k0 + lane;
+                        const uint32_t bv = L.ring[(src + k % dist + shift) & F_MASK];
+                        if (k < len) L.ring[(p + k + shift) & F_MASK] = (uint8_t)bv;
+                        join_lanes();
+                    }
+                }
+                lds_sync();
+                p += len;
+                total += len;
+                prev_v = L.ring[(p - 1 + shift) & F_MASK];
+                mbyte_v = L.ring[(p - 1 - rep0 + shift) & F_MASK];
+            } else if (len < 64) {
+                // dist > len here: lane k takes source byte k, lane len the byte behind the source.  The bytes that
+                // are in HBM only go straight to LDS (the dword around each), and nothing waits for them here.
+                const uint32_t sp = src + (lane <= len ? lane : 0);
+                const bool useg = sp + (F_RING - F_MAX_MATCH) <= p;
+                const uintptr_t a = (uintptr_t)(useg ? ob + sp : safe_byte);
+                pend_sh = useg ? 8 * ((uint32_t)a & 3) : 32;
+                pend_l = L.ring[(sp + shift) & F_MASK];
+                asm volatile("s_mov_b32 m0, %[lds]\n\t"
+                             "s_nop 0\n\t"
+                             "global_load_lds_dword %[a], off sc1"
+                             :
+                             : [lds] "s"(stage_lds), [a] "v"(a & ~(uintptr_t)3)
+                             : "memory", "m0");
+                pend_len = len;
+                pend_p = p;
+                p += len;
+                total += len;
+            } else {
+                for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+                    const uint32_t k = k0 + lane;
+                    const uint32_t sp = src + k;                                   // dist > len
+                    const bool useg = k < len && sp + (F_RING - F_MAX_MATCH) <= p;
+                    const uint32_t gv = __hip_atomic_load(useg ? ob + sp : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t lv = L.ring[(sp + shift) & F_MASK];
+                    if (k < len) L.ring[(p + k + shift) & F_MASK] = (uint8_t)(useg ? gv : lv);
+                    join_lanes();
+                }
+                lds_sync();
+                p += len;
+                total += len;
+                prev_v = L.ring[(p - 1 + shift) & F_MASK];
+                mbyte_v = history_byte_v(p - 1 - rep0);
+            }
+        }
+        if (pend_len) resolve();
+        if (!ok) break;
+        total &= 15;
+        // eof-mode :never at the declared size (lzma.lisp:644-647): the range decoder must be able to finish;
+        // and the chunk must have used exactly its compressed size (lzma2.lisp:200-201)
+        if (code != 0 || s.pos() != chunk_end) { ok = false; break; }
+    }
+#undef BIT
+    if (!ok) { retry(); return; }
+    lds_sync();
+    flush(true);
+
+    // ---- xz block end (xz.lisp:426-457) and results ----
+    semz_tail t{};
+    semz_result r{};
+    const uint32_t real_csize = s.pos() - amis;
+    uint32_t endoff = s.pos();
+    s.slide();
+    if (is_xz) {
+        if (((un.flags & SEMZ_UF_HAVE_IN_SIZE) && real_csize != un.size_in) ||
+            ((un.flags & SEMZ_UF_HAVE_OUT_SIZE) && p != un.size_out)) { retry(); return; }
+        const uint32_t pad = (4 - (real_csize & 3)) & 3;
+        if (endoff + pad > phys_end) { retry(); return; }
+        for (uint32_t k = 0; k < pad; k++)
+            if (s.byte() != 0) { retry(); return; }
+        endoff += pad;
+        const uint32_t ctype = un.param1;
+        const uint32_t cs = ctype == SEMZ_CHECK_CRC32 ? 4 : ctype == SEMZ_CHECK_CRC64 ? 8 : ctype == SEMZ_CHECK_SHA256 ? 32 : 0;
+        t.check_kind = ctype == SEMZ_CHECK_CRC32 ? SEMZ_TK_CRC32 : ctype == SEMZ_CHECK_CRC64 ? SEMZ_TK_CRC64
+                       : ctype == SEMZ_CHECK_SHA256 ? SEMZ_TK_SHA256 : SEMZ_TK_NONE;
+        if (endoff + cs > phys_end) { retry(); return; }
+        t.have_check = 1;
+        const uint8_t *cp = ustart + (endoff - amis);
+        for (uint32_t k = 0; k < cs / 4; k++) {
+            uint32_t v = 0;
+            for (int i = 0; i < 4; i++) v |= (uint32_t)cp[4 * k + i] << (8 * i);
+            t.want[k] = v;
+        }
+        endoff += cs;
+    }
+    const uint64_t end_bit = 8 * (un.in_off + (uint64_t)(endoff - amis));
+    t.trailer_end_bit = end_bit;
+    r.status = SEMZ_OK;
+    r.detail = 0;                          // high word of the compressed size
+    r.aux = real_csize;
+    r.in_end_bit = end_bit;
+    r.out_len = p;
+    r.out_off = un.out_off;
+    if (lane == 0) {
+        results[u] = r;
+        tails[u] = t;
+    }
+}
+
+} // namespace
+
+void semz_launch_lzma2_fast(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits, uint8_t *d_out,
+                            size_t out_cap, semz_result *d_results, semz_tail *d_tails, hipStream_t stream)
+{
+    lzma2_fast_kernel<<<nunits, 64, 0, stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails);
+}

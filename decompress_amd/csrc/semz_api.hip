@@ -128,6 +128,7 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
         return 0;
     }
     if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
+    if (!strcmp(name, "lzma-no-fast")) { c->lz_no_fast = value != 0; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
 }
 

@@ -32,6 +32,7 @@ struct semz_ctx {
     int lz_lc = -1, lz_lp = -1, lz_pb = -1, lz_eof_mode = 0;
     long long lz_size = -1;
     bool lz_honour_size = false;
+    bool lz_no_fast = false;            // option "lzma-no-fast": general kernel only (A/B measurements, tests of the general kernel)
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};
@@ -60,6 +61,10 @@ void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32
 }
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);
+// the accept-only fast path for xz blocks / LZMA2 units (lzma2_fast.hip); what it leaves with the internal retry
+// status is decoded by the general kernels of lzma2.hip
+void semz_launch_lzma2_fast(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits, uint8_t *d_out,
+                            size_t out_cap, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
 // wide: literal probabilities in HBM scratch (SEMZ_UNIT_LZMA_WIDE)
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide);

@@ -175,7 +175,8 @@ int semz_decode_batch_device_noalloc(semz_ctx *ctx, uint32_t kind, const void *d
  * above 2^32-1 are clipped as there), used by semz_decode_stream(SEMZ_FMT_RAW_LZMA2 / _RAW_LZMA).
  * "lc", "lp", "pb", "decompressed-size" (< 0 = nil), "eof-mode" (0 :maybe, 1 :always, 2 :never) = the
  * keywords of the :raw-lzma format (lzma.lisp:809-825).  "lzma-honour-size" = 1 makes SEMZ_FMT_LZMA
- * honour the size its header declares (off = the reference as written). */
+ * honour the size its header declares (off = the reference as written).
+ * "lzma-no-fast" = 1 decodes xz / LZMA2 units with the general kernel only (for measurements). */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */
