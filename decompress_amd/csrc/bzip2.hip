@@ -13,12 +13,14 @@
 //                     Huffman symbols (64-bit windows, every lane a bit offset)
 //                     into an LDS queue, the other expands RLE2 runs and applies
 //                     the inverse MTF (list in a VGPR, DPP shifts)
-//   bz_bwt_kernel     one 1024-thread workgroup per block: byte histogram,
-//                     prefix sums, stable counting-sort scatter that builds the
-//                     merged (next << 8 | byte) vector, then the inverse-BWT walk
-//                     as 4096 concurrent chain segments (walk to measure, link
-//                     the segments in order, walk again to write), de-randomise,
-//                     and the sizing pass of RLE1
+//   bz_sort_kernel    one workgroup per block: byte histogram, prefix sums, stable
+//                     counting-sort scatter that builds the merged (next << 8 | byte)
+//                     vector
+//   bz_walk_kernel    the inverse-BWT walk as up to 4097 concurrent chains per block,
+//                     each writing its bytes to a row of its own; persistent waves,
+//                     one block per XCD at a time so that its vector is walked in L2
+//   bz_link_kernel    one workgroup per block: links the chains in order, copies the
+//                     rows to their places, de-randomises, and sizes RLE1
 //   bz_offsets_kernel exclusive scan of the block output sizes (SEMZ_OUT_AUTO)
 //   bz_rle1_kernel    RLE1 expansion into the final output span
 //   checksum_kernel   (checksums.hip) block CRC and its comparison
@@ -34,16 +36,35 @@ constexpr int BZ_IN_RING = 2 * BZ_IN_HALF;     // ... into a two-piece LDS ring
 constexpr int BZ_GROUP = 50;                   // symbols per selector (bzip2.lisp:222-287)
 constexpr int BZ_AB_BOUND = 19;                // +bzip2-ab-bound+, bzip2.lisp:217-219
 constexpr int BZ_SEGS = 1024;                  // RLE1 segments per block (= threads of bz_bwt_kernel)
-constexpr int BZ_CHAINS = 4096;                // inverse-BWT chain segments per block
-// the walk keeps the first 4 S bytes of every chain (S = marker spacing) in a row of its own: (n / S + 2) rows
-constexpr size_t BZ_TEMP_STRIDE = 4 * (size_t)900032 + 32768;   // + where each long chain goes on (4 B per chain)
-constexpr int BWT_THREADS = 512;               // bz_bwt_kernel: three workgroups fit a CU (49 KB of LDS each), so a
-constexpr int BWT_WAVES = BWT_THREADS / 64;    // 600-block batch is resident at once instead of in two rounds
+constexpr int BZ_CHAINS = 16384;               // inverse-BWT chain starts per block: markers every S = 64 positions at 900 k
+// A chain's bytes go to a row of its own, 4 S bytes long; a chain that is longer goes on in a fresh row under a
+// fresh id: at most n / S + 2 + n / (4 S) + 2 ids, 5 n bytes and a little.
+constexpr int BZ_IDS = 20608;                  // 16386 markers + 4098 continuations at the most, and some
+constexpr int BZ_SUPER = 16;                   // bz_link_kernel: every 16th id heads a run of rows
+constexpr size_t BZ_TEMP_STRIDE = 5 * (size_t)900032 + 65536;
+constexpr int BWT_THREADS = 512;               // bz_sort_kernel, bz_link_kernel: one workgroup per block
+constexpr int BWT_WAVES = BWT_THREADS / 64;
+// bz_walk_kernel: the chip's eight XCDs (one L2 each) take the blocks in turn, so that the one vector an XCD is
+// walking stays in its L2 (scripts/ubench/l2_gather.hip: 3.6 MB gathered at random by one XCD's workgroups stay
+// resident, 245 ns per dependent read; 5 MB do not).
+constexpr int BZ_XCDS = 8;
+constexpr int WALK_WGS = 64;                   // workgroups per XCD: 8192 lanes, one wave on every SIMD
+constexpr int WALK_THREADS = 128;
+constexpr int WALK_STEPS = 4;                  // steps between two refills of a wave's idle lanes
+constexpr int WALK_GRAB = 256;                 // chain starts a wave takes per visit to a block's counter
+
+struct bz_row {            // one row of the walk: how many bytes it holds and which row follows
+    uint32_t len, next;
+};
+// (streaming stores: what the walk writes is not read again by it and must not push the vector out of L2)
+__device__ __forceinline__ void put_row(bz_row *r, uint32_t len, uint32_t next)
+{
+    __builtin_nontemporal_store(((uint64_t)next << 32) | len, reinterpret_cast<uint64_t *>(r));
+}
 
 #ifdef SEMZ_STAMPS
 // diagnostic build only (make STAMPS=1): shader-clock totals of bz_decode_kernel summed over all blocks
 __device__ unsigned long long g_bz_stamps[16];
-__device__ unsigned long long g_bwt_stamps[8];
 #define BZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[5] = {0, 0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
 #define BZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define BZ_COUNT(i) (n_acc[i]++)
@@ -768,10 +789,18 @@ __device__ __forceinline__ uint32_t rle1_step(Rle1 &s, uint32_t b, uint32_t &out
     return b;
 }
 
-__global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz_meta *meta, const uint8_t *pre_all,
-                                                      uint32_t *tt_all, uint8_t *post_all, bz_seg *seg_all, uint8_t *temp_all)
+// Marker spacing of a block of n bytes: the smallest power of two with S * BZ_CHAINS >= n.
+__device__ __forceinline__ uint32_t bz_spacing(uint32_t n)
 {
-    extern __shared__ __align__(16) uint32_t smem[];
+    uint32_t S = 1;
+    while ((uint64_t)S * BZ_CHAINS < n) S <<= 1;
+    return S;
+}
+
+__global__ __launch_bounds__(BWT_THREADS) void bz_sort_kernel(uint32_t nunits, const bz_meta *meta, const uint8_t *pre_all,
+                                                               uint32_t *tt_all)
+{
+    __shared__ __align__(16) uint32_t smem[BWT_WAVES * 256 + 256];
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
     const bz_meta m = meta[u];
@@ -779,16 +808,6 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     const uint32_t n = m.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
     uint32_t *tt = tt_all + (size_t)u * BZ_STRIDE;
-    uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
-    bz_seg *segs = seg_all + (size_t)u * BZ_SEGS;
-    uint8_t *temp = temp_all + (size_t)u * BZ_TEMP_STRIDE;
-
-#ifdef SEMZ_STAMPS
-    uint64_t w_last = __builtin_amdgcn_s_memtime();
-#define BWT_STAMP(i) do { if (tid == 0) { uint64_t t_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_bwt_stamps[i], (unsigned long long)(t_now - w_last)); w_last = t_now; } } while (0)
-#else
-#define BWT_STAMP(i) do { } while (0)
-#endif
     // ---- 1. per-wave byte histograms ----
     uint32_t *hist = smem;                         // [16][256]
     uint32_t *cumm = smem + BWT_WAVES * 256;       // [256]
@@ -857,147 +876,220 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
     }
-    __threadfence_block();
-    __syncthreads();
+}
 
-    BWT_STAMP(0);
-    // ---- 4. inverse BWT walk (bzip2.lisp:158-163) as chain segments ----
-    // out[j] = low byte of tt[k_j], k_0 = origPtr, k_{j+1} = tt[k_j] >> 8.
-    // Markers: k = origPtr (id 0) and k = j*S (id j+1).  Every marker walks until it meets a marker.
-    uint32_t *seg_len = smem;                      // [BZ_CHAINS + 1]
-    uint32_t *seg_next = smem + (BZ_CHAINS + 1);
-    uint32_t *seg_off = smem + 2 * (BZ_CHAINS + 1);
-    uint32_t *misc = smem + 3 * (BZ_CHAINS + 1);   // [0] = cycle length
-    uint32_t S = 1;
-    while ((uint64_t)S * BZ_CHAINS < n) S <<= 1;
-    const uint32_t nreg = n ? (n + S - 1) / S : 0; // regular markers 0, S, 2S, ...
-    const uint32_t nmark = nreg + 1;
-    const uint32_t orig = m.orig;
-    for (uint32_t i = tid; i < nmark; i += BWT_THREADS) seg_off[i] = 0xFFFFFFFFu;
-    // The walk costs one random 4-byte read (a whole HBM line) per output byte and it is what bounds this kernel,
-    // so it is done once: while a chain is measured its bytes go to the chain's own row of `temp` (4 S bytes; chain
-    // lengths are spread geometrically around S, 2 % are longer), and once the chains are linked the rows are
-    // copied to their places with coalesced accesses.  Only the chains longer than a row are walked a second time.
-    const uint32_t CAP = 4 * S;
-    uint32_t *resume = reinterpret_cast<uint32_t *>(temp + (size_t)nmark * CAP);   // k after CAP steps, per chain
-    if (n) {
-        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
-            uint32_t k[4], len[4], acc[4];
-            uint32_t *row[4];
-            bool act[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * BWT_THREADS;
-                act[c] = id < nmark;
-                k[c] = id == 0 ? orig : (id - 1) * S;
-                len[c] = 0;
-                acc[c] = 0;
-                row[c] = reinterpret_cast<uint32_t *>(temp + (size_t)id * CAP);
-            }
-            bool any = true;
-            while (any) {
-                any = false;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if (!act[c]) continue;
-                    const uint32_t v = tt[k[c]];
-                    if (len[c] < CAP) {
-                        acc[c] |= (v & 0xFF) << (8 * (len[c] & 3));
-                        if ((len[c] & 3) == 3) { row[c][len[c] >> 2] = acc[c]; acc[c] = 0; }
-                    }
-                    const uint32_t nk = v >> 8;
-                    len[c]++;
-                    k[c] = nk;
-                    if (len[c] == CAP) resume[id0 + c * BWT_THREADS] = nk;
-                    if (nk == orig || (nk & (S - 1)) == 0) {
-                        act[c] = false;
-                        if (len[c] <= CAP && (len[c] & 3)) row[c][len[c] >> 2] = acc[c];
-                    } else any = true;
+// ---- 4. inverse BWT walk (bzip2.lisp:158-163) ----
+// out[j] = low byte of tt[k_j], k_0 = origPtr, k_{j+1} = tt[k_j] >> 8: one dependent random 4-byte read per output
+// byte.  Markers: k = origPtr (id 0) and k = j S (id j + 1); every marker walks until it meets a marker, its bytes go
+// to row `id` of the block's `temp` (4 S bytes; chain lengths are spread geometrically around S), and a chain that
+// fills its row goes on in a fresh row under a fresh id.  rows[id] = {bytes, following row}.
+//
+// What bounds the walk is where the vector lives.  With every block of a batch walked at once (the first version)
+// each read fetched a whole 128-byte line from HBM, 71 GB for 540 MB of output.  Here an XCD walks one block at a
+// time, more or less: a wave takes chain starts from the counter of the block its XCD is at and moves to the XCD's
+// next block (+ 8) when that counter runs out, a lane whose chain has ended takes the next start at once.  Chains
+// are short (S = 64) so that the lanes still busy with a block when the others have moved on hold the smaller
+// part of its steps, and the vector of the block in hand (3.6 MB) mostly stays in the XCD's 4 MB L2: 83 % of the
+// kernel's L2 requests hit (TCC_HIT / TCC_REQ), where 94 % missed before.  Measured on the 600-block bench:
+// S = 16 / 64 / 256 walk in 8.1 / 8.6 / 12.6 ms and link in 8.0 / 5.2 / 6.0 ms (short rows waste lines there).
+__global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, const bz_meta *meta, const uint32_t *tt_all,
+                                                                uint8_t *temp_all, bz_row *rows_all, uint32_t *ctl)
+{
+    // which XCD this workgroup landed on (XCC_ID, hardware register 20, bits 3:0).  Only the affinity hangs on it:
+    // a wave that finds no block left on its XCD's list goes through the other lists, so every block is walked
+    // wherever the workgroups were placed.
+    const uint32_t home = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) % BZ_XCDS;
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t *starts = ctl;                        // per block: chain starts handed out
+    uint32_t *extra = ctl + nunits;                // per block: ids handed out beyond the markers
+    // the block in hand (wave-uniform)
+    uint32_t cur = home, lists = 0;                // block index; lists (XCDs) finished so far
+    uint32_t c_nmark = 0, c_S = 1, c_orig = 0;
+    uint32_t next = 0, end = 0;                    // this wave's share of the block's starts
+    bool exhausted = false, loaded = false;
+    // the chain in hand (per lane)
+    bool active = false;
+    uint32_t k = 0, len = 0, id = 0, acc = 0, smask = 0, sshift = 0, orig = 0, cap = 0, nmark = 0, blk = 0;
+    const uint32_t *tt = tt_all;
+    uint32_t *row = nullptr;
+    bz_row *rows = nullptr;
+    uint8_t *temp = nullptr;
+    for (;;) {
+        const uint64_t idle = __ballot(!active);
+        if (idle) {
+            while (next >= end && !exhausted) {
+                if (cur >= nunits) {               // this list is done: on to the next XCD's
+                    if (++lists == (uint32_t)BZ_XCDS) { exhausted = true; break; }
+                    cur = (home + lists) % BZ_XCDS;
+                    loaded = false;
+                    continue;
+                }
+                if (!loaded) {
+                    const uint32_t n = meta[cur].n;
+                    c_S = bz_spacing(n);
+                    c_nmark = meta[cur].status == SEMZ_OK && n ? (n + c_S - 1) / c_S + 1 : 0;
+                    c_orig = meta[cur].orig;
+                    loaded = true;
+                }
+                uint32_t base = 0xFFFFFFFFu;
+                if (c_nmark) {
+                    if (lane == 0) base = atomicAdd(&starts[cur], (uint32_t)WALK_GRAB);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                }
+                if (base >= c_nmark) {
+                    cur += BZ_XCDS;
+                    loaded = false;
+                } else {
+                    next = base;
+                    end = base + WALK_GRAB < c_nmark ? base + WALK_GRAB : c_nmark;
                 }
             }
+            const uint32_t room = end - next;
+            if (!active) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
+                if (rank < room) {
+                    const uint32_t c = next + rank;
+                    active = true;
+                    blk = cur;
+                    nmark = c_nmark;
+                    smask = c_S - 1;
+                    sshift = (uint32_t)__builtin_ctz(c_S);
+                    cap = 4 * c_S;
+                    orig = c_orig;
+                    id = c;
+                    k = c == 0 ? c_orig : (c - 1) * c_S;
+                    len = 0;
+                    acc = 0;
+                    tt = tt_all + (size_t)cur * BZ_STRIDE;
+                    temp = temp_all + (size_t)cur * BZ_TEMP_STRIDE;
+                    rows = rows_all + (size_t)cur * BZ_IDS;
+                    row = reinterpret_cast<uint32_t *>(temp + (size_t)id * cap);
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            next += want < room ? want : room;
+            if (exhausted && __ballot(active) == 0) break;
+        }
+        // a few steps between two looks at the idle lanes (a chain that ends waits two steps on average)
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * BWT_THREADS;
-                if (id < nmark) {
-                    seg_len[id] = len[c];
-                    seg_next[id] = k[c] == orig ? 0 : k[c] / S + 1;
+        for (int st = 0; st < WALK_STEPS; st++) {
+            if (active) {
+                const uint32_t v = tt[k];
+                acc |= (v & 0xFF) << (8 * (len & 3));
+                if ((len & 3) == 3) { __builtin_nontemporal_store(acc, &row[len >> 2]); acc = 0; }
+                k = v >> 8;
+                len++;
+                if (k == orig || (k & smask) == 0) {
+                    if (len & 3) __builtin_nontemporal_store(acc, &row[len >> 2]);
+                    put_row(&rows[id], len, k == orig ? 0u : (k >> sshift) + 1);
+                    active = false;
+                } else if (len == cap) {
+                    const uint32_t nid = nmark + atomicAdd(&extra[blk], 1u);
+                    if (nid < (uint32_t)BZ_IDS) {
+                        put_row(&rows[id], cap, nid);
+                        id = nid;
+                        len = 0;
+                        row = reinterpret_cast<uint32_t *>(temp + (size_t)id * cap);
+                    } else {                       // cannot happen (BZ_IDS covers n / S + 2 + n / (4 S) + 2); ends the list
+                        put_row(&rows[id], cap, 0xFFFFFFFFu);
+                        active = false;
+                    }
                 }
             }
         }
     }
-    __threadfence_block();
+}
+
+// The rows in walk order, to their places in `post`.  There are tens of thousands of rows per block, so the list
+// is ranked in two levels: every id that is a multiple of BZ_SUPER heads a run of rows (id 0, origPtr's row, is
+// one of them); a thread follows each run to the next head and sums its bytes, one thread puts the runs in
+// order, then each run is followed again and its rows are copied.
+__global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, bz_meta *meta, uint8_t *post_all,
+                                                               bz_seg *seg_all, const uint8_t *temp_all, const bz_row *rows_all,
+                                                               const uint32_t *ctl)
+{
+    constexpr uint32_t LINK_WORDS = 3 * (BZ_IDS / BZ_SUPER + 1) + 16 > 10 * BZ_SEGS ? 3 * (BZ_IDS / BZ_SUPER + 1) + 16 : 10 * BZ_SEGS;
+    __shared__ __align__(16) uint32_t smem[LINK_WORDS];
+    const uint32_t u = blockIdx.x;
+    if (u >= nunits) return;
+    const bz_meta m = meta[u];
+    if (m.status != SEMZ_OK) return;
+    const uint32_t n = m.n, tid = threadIdx.x;
+    uint8_t *post = post_all + (size_t)u * BZ_STRIDE;
+    bz_seg *segs = seg_all + (size_t)u * BZ_SEGS;
+    const uint8_t *temp = temp_all + (size_t)u * BZ_TEMP_STRIDE;
+    const bz_row *rows = rows_all + (size_t)u * BZ_IDS;
+    constexpr uint32_t NRUN = BZ_IDS / BZ_SUPER + 1;
+    uint32_t *run_len = smem;                      // [NRUN] bytes in the run headed by id BZ_SUPER * r
+    uint32_t *run_next = smem + NRUN;              // the run that follows (0xFFFFFFFF: the list breaks off)
+    uint32_t *run_off = smem + 2 * NRUN;           // where the run's bytes go; 0xFFFFFFFF = not on origPtr's cycle
+    uint32_t *misc = smem + 3 * NRUN;              // [0] = cycle length
+    const uint32_t S = bz_spacing(n);
+    const uint32_t CAP = 4 * S;
+    uint32_t nids = n ? (n + S - 1) / S + 1 + ctl[nunits + u] : 0;
+    if (nids > (uint32_t)BZ_IDS) nids = BZ_IDS;
+    const uint32_t nrun = (nids + BZ_SUPER - 1) / BZ_SUPER;
+    for (uint32_t r = tid; r < nrun; r += BWT_THREADS) {
+        uint32_t id = r * BZ_SUPER, sum = 0, nx = 0xFFFFFFFFu;
+        for (uint32_t guard = 0; guard < nids; guard++) {          // (a run ends at the next head; the guard is belt and braces)
+            const bz_row w = rows[id];
+            sum += w.len;
+            nx = w.next;
+            if (nx >= nids) { nx = 0xFFFFFFFFu; break; }
+            if (nx % BZ_SUPER == 0) { nx /= BZ_SUPER; break; }
+            id = nx;
+            nx = 0xFFFFFFFFu;
+        }
+        run_len[r] = sum;
+        run_next[r] = nx;
+        run_off[r] = 0xFFFFFFFFu;
+    }
     __syncthreads();
-    BWT_STAMP(1);
     if (tid == 0) {
         uint32_t t = 0, off = 0;
-        while (off < n && seg_off[t] == 0xFFFFFFFFu) {
-            seg_off[t] = off;
-            off += seg_len[t];
-            t = seg_next[t];
+        while (off < n && t < nrun && run_off[t] == 0xFFFFFFFFu) {
+            run_off[t] = off;
+            off += run_len[t];
+            t = run_next[t];
         }
         misc[0] = off;                              // >= n, or the length of origPtr's cycle if shorter
     }
     __syncthreads();
-    BWT_STAMP(2);
     const uint32_t cyc = misc[0];
     const uint32_t wlim = cyc < n ? cyc : n;
-    if (n) {
-        // rows to their places, one chain per wave at a time, four 64-byte pieces in flight
-        for (uint32_t id = wave; id < nmark; id += BWT_WAVES) {
-            const uint32_t so = seg_off[id];
-            if (so == 0xFFFFFFFFu) continue;
-            uint32_t ln = seg_len[id];
-            if (ln > CAP) ln = CAP;
-            if (so + ln > wlim) ln = so < wlim ? wlim - so : 0;
-            const uint8_t *src = temp + (size_t)id * CAP;
-            for (uint32_t j0 = 0; j0 < ln; j0 += 256) {
-                uint8_t b[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t j = j0 + 64 * q + lane;
-                    b[q] = j < ln ? src[j] : (uint8_t)0;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t j = j0 + 64 * q + lane;
-                    if (j < ln) post[so + j] = b[q];
-                }
+    // Each run is followed again and its rows are copied: whole dwords to whatever address they belong at (the
+    // hardware takes unaligned dword stores), single bytes at a row's end.
+    for (uint32_t r = tid; r < nrun; r += BWT_THREADS) {
+        uint32_t so = run_off[r];
+        if (so == 0xFFFFFFFFu) continue;
+        uint32_t id = r * BZ_SUPER;
+        for (uint32_t guard = 0; guard < nids && so < wlim; guard++) {
+            const bz_row w = rows[id];
+            uint32_t ln = w.len < CAP ? w.len : CAP;
+            if (so + ln > wlim) ln = wlim - so;
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(temp + (size_t)id * CAP);
+            uint8_t *dst = post + so;
+            uint32_t j = 0;
+            for (; j + 4 <= ln; j += 4) {
+                const uint32_t x = src[j >> 2];
+                __builtin_memcpy(dst + j, &x, 4);
             }
-        }
-        // the long chains go on from where their row ended, straight to their places
-        for (uint32_t id0 = tid; id0 < nmark; id0 += 4 * BWT_THREADS) {
-            uint32_t k[4], o[4], e[4];
-            bool act[4];
-            bool any = false;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                uint32_t id = id0 + c * BWT_THREADS;
-                act[c] = id < nmark && seg_off[id] != 0xFFFFFFFFu && seg_len[id] > CAP;
-                k[c] = act[c] ? resume[id] : 0;
-                o[c] = act[c] ? seg_off[id] + CAP : 0;
-                e[c] = act[c] ? seg_off[id] + seg_len[id] : 0;
-                any = any || act[c];
+            if (j < ln) {
+                uint32_t x = src[j >> 2];
+                for (; j < ln; j++, x >>= 8) dst[j] = (uint8_t)x;
             }
-            while (any) {
-                any = false;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if (!act[c]) continue;
-                    uint32_t v = tt[k[c]];
-                    if (o[c] < wlim) post[o[c]] = (uint8_t)v;
-                    k[c] = v >> 8;
-                    o[c]++;
-                    if (o[c] >= e[c]) act[c] = false;
-                    else any = true;
-                }
-            }
+            so += w.len;
+            const uint32_t nx = w.next;
+            if (nx >= nids || nx % BZ_SUPER == 0) break;
+            id = nx;
         }
     }
     __threadfence_block();
     __syncthreads();
     if (cyc < n) {
         // origPtr's cycle is shorter than the block: the output is periodic
-        for (uint32_t j = cyc + tid; j < n; j += BWT_THREADS) post[j] = post[j % cyc];
+        if (cyc)
+            for (uint32_t j = cyc + tid; j < n; j += BWT_THREADS) post[j] = post[j % cyc];
         __threadfence_block();
         __syncthreads();
     }
@@ -1014,7 +1106,6 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
     __threadfence_block();
     __syncthreads();
 
-    BWT_STAMP(3);
     // ---- 6. RLE1 sizing: every thread parses its segment from each of the five
     //         possible entry classes; thread 0 then chains the real states ----
     // classes: 0 fresh (last != first byte, reps < 3), 1 count byte expected (reps == 3),
@@ -1055,7 +1146,6 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
         }
     }
     __syncthreads();
-    BWT_STAMP(4);
     if (tid == 0) {
         Rle1 st = {-1, 0};
         uint64_t off = 0;
@@ -1077,8 +1167,6 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_bwt_kernel(uint32_t nunits, bz
         }
         meta[u].out_len = off;
     }
-    BWT_STAMP(5);
-#undef BWT_STAMP
 }
 
 // Exclusive scan of the block sizes for SEMZ_OUT_AUTO units, capacity checks, results and tails.
@@ -1184,13 +1272,6 @@ __global__ __launch_bounds__(1024) void bz_rle1_kernel(uint32_t nunits, const bz
 extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
 {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bz_stamps), sizeof(g_bz_stamps)) != hipSuccess) return -1;
-    {
-        unsigned long long w[8];
-        if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_bwt_stamps), sizeof w) != hipSuccess) return -1;
-        printf("bz_bwt_kernel Mticks summed over blocks: hist+scatter %.1f  walk-measure %.1f  link %.1f  walk-write %.1f  rle1-size %.1f  rle1-chain %.1f\n",
-               w[0] / 1e6, w[1] / 1e6, w[2] / 1e6, w[3] / 1e6, w[4] / 1e6, w[5] / 1e6);
-        if (reset) { unsigned long long z8[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_bwt_stamps), z8, sizeof z8); }
-    }
     if (reset) {
         unsigned long long z[16] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_bz_stamps), z, sizeof z) != hipSuccess) return -1;
@@ -1207,21 +1288,27 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_META, (size_t)nunits * sizeof(bz_meta), &meta))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_DATA, (size_t)nunits * BZ_STRIDE * 2, &pre))) return rc;
     if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_TT, (size_t)nunits * (BZ_STRIDE * sizeof(uint32_t) + BZ_TEMP_STRIDE), &tt))) return rc;
-    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, (size_t)nunits * BZ_SEGS * sizeof(bz_seg), &segs))) return rc;
+    // RLE1 segment states, then the walk's rows (length, successor), then its counters (two per block)
+    const size_t segs_bytes = (size_t)nunits * BZ_SEGS * sizeof(bz_seg);
+    const size_t rows_bytes = (size_t)nunits * BZ_IDS * sizeof(bz_row);
+    const size_t ctl_bytes = 2 * (size_t)nunits * sizeof(uint32_t);
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, segs_bytes + rows_bytes + ctl_bytes, &segs))) return rc;
+    bz_row *rows = (bz_row *)((uint8_t *)segs + segs_bytes);
+    uint32_t *ctl = (uint32_t *)((uint8_t *)rows + rows_bytes);
     post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
-    const size_t smem = (3 * (BZ_CHAINS + 1) + 16) * sizeof(uint32_t);
-    if (!c->bz_attr_set) {                      // per context, i.e. per device
-        if (hipFuncSetAttribute((const void *)bz_bwt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return semz_fail(c, -2, "cannot reserve %zu bytes of LDS for bz_bwt_kernel", smem);
-        c->bz_attr_set = true;
-    }
+    uint8_t *temp = (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t);
+    if (hipMemsetAsync(ctl, 0, ctl_bytes, c->stream) != hipSuccess) return semz_fail(c, -2, "hipMemsetAsync failed");
     semz_span_begin(c, "bz_decode_kernel");
     bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre);
     semz_span_end(c);
-    semz_span_begin(c, "bz_bwt_kernel");
-    bz_bwt_kernel<<<nunits, BWT_THREADS, smem, c->stream>>>(nunits, (bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt,
-                                                     (uint8_t *)post, (bz_seg *)segs,
-                                                     (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t));
+    semz_span_begin(c, "bz_sort_kernel");
+    bz_sort_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt);
+    semz_span_end(c);
+    semz_span_begin(c, "bz_walk_kernel");
+    bz_walk_kernel<<<BZ_XCDS * WALK_WGS, WALK_THREADS, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint32_t *)tt, temp, rows, ctl);
+    semz_span_end(c);
+    semz_span_begin(c, "bz_link_kernel");
+    bz_link_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (bz_meta *)meta, (uint8_t *)post, (bz_seg *)segs, temp, rows, ctl);
     semz_span_end(c);
     semz_span_begin(c, "bz_offsets_kernel");
     bz_offsets_kernel<<<1, 64, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);

@@ -21,7 +21,6 @@ struct semz_ctx {
     semz_check_tables *d_tabs = nullptr;
     // this device's copy of the static scratch array of semz_decode_batch_device_noalloc (hipGetSymbolAddress)
     void *noalloc_scratch = nullptr;
-    bool bz_attr_set = false;           // bz_bwt_kernel's LDS size has been raised on this device
     std::vector<semz_devbuf> bufs;      // grow-only scratch, indexed by SEMZ_SLOT_*
     // optional per-kernel timing (semz_set_option "profile"): event pairs on `stream`
     bool profile = false;
