@@ -130,21 +130,62 @@ def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64", replic
                 out_cap=total_out + 4096, sample_out=unit_bytes)
 
 
-def cpu_baseline(fmt, blobs, sample_out, budget_s=12.0):
-    """Oracle (CPU port of the reference algorithm) on a bounded sample, one core."""
+_CPU_FMT = {"gzip": 2, "zlib": 1, "bzip2": 3, "xz": 8}
+
+
+def _oracle_worker(args):
+    """One core: decode blobs[lo::stride] round and round through oracle/ until the budget is spent."""
+    fmt, blobs, sample_out, budget_s, start = args
     from oracle import oracle
-    fmt_id = {"gzip": 2, "zlib": 1, "bzip2": 3, "xz": 8}[fmt]
     t0 = time.perf_counter()
     done = 0
-    while time.perf_counter() - t0 <= budget_s:            # a bounded sample: about budget_s of CPU work
-        b = blobs[done % len(blobs)]
-        r, o = oracle.decompress(fmt_id, b, True, cap=sample_out + 16)
+    while time.perf_counter() - t0 <= budget_s:
+        b = blobs[(start + done) % len(blobs)]
+        r, o = oracle.decompress(_CPU_FMT[fmt], b, True, cap=sample_out + 16)
         assert r.status == 0 and len(o) == sample_out
         done += 1
+    return done, time.perf_counter() - t0
+
+
+def _tool_rate(tool, blob_concat, out_bytes):
+    """`tool -dc` over concatenated members / streams, one process (what a user without either library would run)."""
+    import shutil
+    import subprocess
+    if not shutil.which(tool):
+        return None
+    t0 = time.perf_counter()
+    p = subprocess.run([tool, "-dc"], input=blob_concat, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     dt = time.perf_counter() - t0
-    return {"value": done * sample_out / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{done} decodes cycling over the same {fmt} inputs ({done * sample_out / 2**20:.0f} MiB out) through oracle/ "
-                      f"(C restatement of the reference), 1 thread, {dt:.1f} s"}
+    return round(out_bytes / dt / 1e9, 4) if p.returncode == 0 else None
+
+
+def cpu_baseline(fmt, blobs, sample_out, ncores, budget_s=8.0):
+    """CPU rates on the GPU box's host cores, all on bounded samples of the same workload and all before the GPU is
+    initialised (the workers are forked).  `value` is the oracle (C restatement of the reference's algorithm) on
+    every core of this process's CPU share; `single` is one core of it; `proxies` are the system tools, one process
+    each.  The reference itself is Common Lisp and no Lisp implementation exists on this box."""
+    import shutil
+    sample = blobs[:max(1, min(len(blobs), 4 * ncores))]
+    one, dt1 = _oracle_worker((fmt, sample, sample_out, budget_s, 0))
+    jobs = [(fmt, sample, sample_out, budget_s, i) for i in range(ncores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(ncores) as pool:
+        parts = pool.map(_oracle_worker, jobs)
+    wall = time.perf_counter() - t0
+    alln = sum(d for d, _ in parts)
+    tool = {"gzip": "gzip", "zlib": None, "bzip2": "bzip2", "xz": "xz"}[fmt]
+    proxies = {}
+    if tool:
+        k = max(1, min(len(sample), (256 << 20) // max(1, sample_out)))      # at most 256 MiB of output through the tool
+        proxies[f"{tool} -dc (1 process)"] = _tool_rate(tool, b"".join(sample[:k]), k * sample_out)
+    return {"value": round(alln * sample_out / wall / 1e9, 4), "unit": "GB/s", "cores": ncores, "kind": "port",
+            "single": round(one * sample_out / dt1 / 1e9, 4), "all_cores": round(alln * sample_out / wall / 1e9, 4),
+            "sbcl": "unavailable on this box (no Common Lisp implementation in the image): the reference itself cannot be timed",
+            "proxies_GBps": proxies,
+            "sample": f"oracle/ (C restatement of the reference) over {len(sample)} of the bench's {fmt} inputs, cycled: "
+                      f"1 thread did {one} decodes ({one * sample_out / 2**20:.0f} MiB out) in {dt1:.1f} s; {ncores} forked workers "
+                      f"did {alln} decodes ({alln * sample_out / 2**20:.0f} MiB out) in {wall:.1f} s wall; system tool on "
+                      f"{'%d' % (k if tool else 0)} concatenated inputs"}
 
 
 def main():
@@ -175,15 +216,15 @@ def main():
         nunits, unit_bytes = a.units or 4096, a.unit_bytes or 262144
         workload = f"{nunits} independent {unit_bytes // 1024} KiB gzip -6 members per GPU (BASELINE configs[1]), CRC-32 + ISIZE verified"
     elif a.format == "zlib":
-        nunits, unit_bytes = a.units or (1 << 18), a.unit_bytes or 4096
-        workload = f"{nunits} zlib -6 records of {unit_bytes} B per GPU (BASELINE configs[4] shape), Adler-32 verified"
+        nunits, unit_bytes = a.units or (1 << 20), a.unit_bytes or 4096
+        workload = f"{nunits} zlib -6 records of {unit_bytes} B per GPU (BASELINE configs[4]), Adler-32 verified"
     elif a.format == "bzip2":
         nunits, unit_bytes = a.units or 8, a.unit_bytes or (64 << 20)
         workload = (f"{nunits} bzip2 -9 streams of {unit_bytes >> 20} MiB per GPU, block-parallel "
                     "(BASELINE configs[2] shape: 512 MiB of the 4 GiB per GPU), block and stream CRCs verified")
     else:
-        nunits, unit_bytes = a.units or 16, a.unit_bytes or (16 << 20)
-        a.replicate = a.replicate or 8
+        nunits, unit_bytes = a.units or 64, a.unit_bytes or (16 << 20)
+        a.replicate = a.replicate or 2
         workload = (f"{nunits * a.replicate} xz streams of {unit_bytes >> 20} MiB per GPU ({nunits} distinct, each {a.replicate} times), "
                     f"1 MiB LZMA2 blocks + x86 BCJ, check {a.check} verified (BASELINE configs[3] shape)")
     rep = max(1, a.replicate) if a.format in ("bzip2", "xz") else 1
@@ -198,12 +239,16 @@ def main():
     t_gen = time.perf_counter() - t_gen
     data, uarr, nun, total_out, total_in, kind, blobs = (W[k] for k in ("data", "uarr", "nunits", "total_out", "total_in", "kind", "blobs"))
 
-    # GPU initialisation only after the corpus workers (forked) are gone
+    # CPU baseline (forked workers) and then GPU initialisation, in that order
+    cpu_line = None
+    if not a.no_cpu and world == 1 and rank == 0:
+        cpu_line = cpu_baseline(a.format, blobs, W["sample_out"], max(1, min(16, ncpu)))
     if world > 1:
+        # the path has no exchange step: the process group only carries the barrier and the max over ranks, on the
+        # host (gloo), so RCCL is not even loaded
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
 
     eng = _lib.Engine(local)
     d_in = eng.dev_alloc(total_in + 64)
@@ -217,10 +262,8 @@ def main():
         eng.decode_batch_device(kind, d_in, total_in, d_units, nun, d_out, W["out_cap"], d_res)
 
     def barrier():
-        eng.sync()
+        eng.sync()                                  # hipStreamSynchronize on the engine's stream + hipDeviceSynchronize
         if dist is not None:
-            import torch
-            torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(a.warmup):
@@ -237,7 +280,7 @@ def main():
     eng.set_option("profile", 0)
     if dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -311,8 +354,8 @@ def main():
             e2e = min(c_call(), c_call())
             line["end_to_end"] = {"value": round(total_out / e2e / 1e9, 3), "unit": "GB/s", "ms": round(e2e * 1e3, 2),
                                   "path": "one semz_decode_stream call on pageable host buffers: host split, H2D, kernels, D2H into a fresh buffer; never `value`"}
-        if not a.no_cpu and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.format, blobs, W["sample_out"])
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
 
     for p in (d_in, d_units, d_out, d_res):
