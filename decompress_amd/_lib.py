@@ -57,7 +57,7 @@ OUT_AUTO = 0xFFFFFFFFFFFFFFFF
 _lib = None
 
 EXPORTS = [
-    "semz_open", "semz_close", "semz_last_error", "semz_strerror", "semz_decode_batch",
+    "semz_open", "semz_open_multi", "semz_device_count", "semz_close", "semz_last_error", "semz_strerror", "semz_decode_batch",
     "semz_decode_batch_device", "semz_decode_batch_device_noalloc", "semz_set_option", "semz_sync", "semz_stream",
     "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
     "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
@@ -79,6 +79,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
     lib.semz_open.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.semz_open_multi.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.semz_device_count.argtypes = [vp]
     lib.semz_close.argtypes = [vp]
     lib.semz_close.restype = None
     lib.semz_last_error.argtypes = [vp]
@@ -129,16 +131,25 @@ class EngineError(RuntimeError):
 
 
 class Engine:
-    """One context on one GPU (semz_open / semz_close)."""
+    """One context on one GPU (semz_open), or on several (semz_open_multi: `device` a list whose first entry is
+    the primary device; the stream calls then spread every predicted batch over all of them)."""
 
     def __init__(self, device=0):
         self.lib = load()
         h = C.c_void_p()
-        rc = self.lib.semz_open(device, C.byref(h))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*device)
+            rc = self.lib.semz_open_multi(devs, len(device), C.byref(h))
+        else:
+            rc = self.lib.semz_open(device, C.byref(h))
         if rc != 0:
             raise EngineError(f"semz_open(device={device}) failed with {rc}: no usable MI355X; "
                               "this library has no CPU fallback")
         self.h = h
+
+    @property
+    def device_count(self):
+        return self.lib.semz_device_count(self.h)
 
     def close(self):
         if self.h:

@@ -94,9 +94,32 @@ extern "C" int semz_open(int device, semz_ctx **out)
     return 0;
 }
 
+extern "C" int semz_open_multi(const int *devices, int ndev, semz_ctx **out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    if (!devices || ndev < 1 || ndev > 255) return -1;
+    semz_ctx *c = nullptr;
+    int rc = semz_open(devices[0], &c);
+    if (rc) return rc;
+    for (int i = 1; i < ndev; i++) {
+        semz_ctx *h = nullptr;
+        rc = semz_open(devices[i], &h);
+        if (rc) { semz_close(c); return rc; }
+        c->helpers.push_back(h);
+    }
+    hipSetDevice(c->device);
+    *out = c;
+    return 0;
+}
+
+extern "C" int semz_device_count(const semz_ctx *c) { return c ? 1 + (int)c->helpers.size() : 0; }
+
 extern "C" void semz_close(semz_ctx *c)
 {
     if (!c) return;
+    for (semz_ctx *h : c->helpers) semz_close(h);
+    c->helpers.clear();
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     semz_profile_reset(c);
@@ -111,6 +134,7 @@ extern "C" const char *semz_last_error(const semz_ctx *c) { return c ? c->err : 
 extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
 {
     if (!c || !name) return -1;
+    for (semz_ctx *h : c->helpers) (void)semz_set_option(h, name, value);      // the other devices of semz_open_multi follow
     if (!strcmp(name, "profile")) { c->profile = value != 0; return 0; }
     if (!strcmp(name, "window-size")) {
         if (value < 0) return semz_fail(c, -1, "window-size must be an unsigned integer");   // check-type, lzma2.lisp:212

@@ -32,6 +32,8 @@ struct semz_ctx {
     long long lz_size = -1;
     bool lz_honour_size = false;
     bool lz_no_fast = false;            // option "lzma-no-fast": general kernel only (A/B measurements, tests of the general kernel)
+    // semz_open_multi: contexts on the other devices; the stream calls spread a predicted batch over all of them
+    std::vector<semz_ctx *> helpers;
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};

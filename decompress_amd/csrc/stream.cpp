@@ -17,8 +17,10 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <thread>
 #include <vector>
 #include "container.h"
+#include "multi.h"
 #include "semz_host.h"
 
 using namespace semz;
@@ -46,6 +48,20 @@ struct Run {
     std::vector<Span> spans;                   // output of the stream, in order, as arena spans
     uint64_t emitted = 0;                      // bytes in `spans`
     std::vector<semz_member> members;          // members the walk has completed, in order
+    // The other devices of a context opened with semz_open_multi: each decodes a contiguous range of a predicted
+    // batch from the bytes of that range and keeps the output in an arena of its own; offsets into it carry the
+    // helper's index (1..) in their top byte (multi.h).  Everything the walk decodes on demand runs on the
+    // primary device, which holds the whole input.
+    struct Helper {
+        semz_ctx *c = nullptr;
+        uint8_t *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0, out_used = 0;
+        semz_unit *d_units = nullptr;
+        semz_result *d_res = nullptr;
+        size_t unit_cap = 0;
+    };
+    std::vector<Helper> helpers;
+    std::vector<uint8_t> distrust;             // per unit of the last decode(): the result must not be used (see multi.h)
 
     ~Run()
     {
@@ -53,12 +69,25 @@ struct Run {
         if (d_out) (void)hipFree(d_out);
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
+        for (auto &h : helpers) {
+            (void)hipSetDevice(h.c->device);
+            if (h.d_in) (void)hipFree(h.d_in);
+            if (h.d_out) (void)hipFree(h.d_out);
+            if (h.d_units) (void)hipFree(h.d_units);
+            if (h.d_res) (void)hipFree(h.d_res);
+        }
+        if (!helpers.empty()) (void)hipSetDevice(c->device);
     }
     int open()
     {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipMalloc((void **)&d_in, in_len + 64));
         HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+        for (semz_ctx *hc : c->helpers) {
+            Helper h;
+            h.c = hc;
+            helpers.push_back(h);
+        }
         return 0;
     }
     // Sizes that come out of the data (declared sizes, index records, ISIZE fields) are untrusted: a request the
@@ -92,12 +121,37 @@ struct Run {
     {
         const size_t n = units.size();
         res.assign(n, semz_result{});
+        distrust.assign(n, 0);
         if (!n) return 0;
         // every fixed span must lie inside the room this call hands to the kernels (they check it again per unit)
         if (arena_base > out_cap || arena_room > out_cap - arena_base) return semz_fail(c, -4, "internal: arena room beyond the arena");
         for (auto &u : units)
             if (u.out_off != SEMZ_OUT_AUTO && (u.out_off > arena_room || u.out_cap > arena_room - u.out_off))
                 return semz_fail(c, -4, "internal: unit span beyond the arena room");
+        // one input, several devices: contiguous ranges of the batch, one per device, side by side
+        std::vector<MultiRange> ranges;
+        if (!helpers.empty() && n >= 2 * (helpers.size() + 1) && in_len >= (1u << 20))
+            ranges = partition_units(units.data(), n, in_len, (unsigned)helpers.size() + 1, 1u << 16, arena_room);
+        if (ranges.size() < 2) return decode_on_primary(units.data(), n, res.data(), arena_base, arena_room);
+        std::vector<int> rcs(ranges.size(), 0);
+        std::vector<std::thread> th;
+        for (size_t p = 1; p < ranges.size(); p++)
+            th.emplace_back([&, p] { rcs[p] = decode_on_helper(helpers[p - 1], (unsigned)p, units.data(), ranges[p], arena_base, res.data()); });
+        rcs[0] = decode_on_primary(units.data(), ranges[0].count, res.data(), arena_base, arena_room);
+        for (auto &t : th) t.join();
+        HIPCHK(c, hipSetDevice(c->device));
+        for (size_t p = 0; p < ranges.size(); p++) {
+            if (rcs[p] == RC_OOM) {                 // a helper without the memory: its range is decoded by the walk, on demand
+                for (size_t i = 0; i < ranges[p].count; i++) distrust[ranges[p].first + i] = 1;
+            } else if (rcs[p]) {
+                if (p) semz_fail(c, rcs[p], "device %d: %s", helpers[p - 1].c->device, helpers[p - 1].c->err);
+                return rcs[p];
+            }
+        }
+        return 0;
+    }
+    int decode_on_primary(const semz_unit *units, size_t n, semz_result *res, uint64_t arena_base, uint64_t arena_room)
+    {
         if (n > unit_cap) {
             if (d_units) HIPCHK(c, hipFree(d_units));
             if (d_res) HIPCHK(c, hipFree(d_res));
@@ -106,12 +160,62 @@ struct Run {
             HIPCHK(c, hipMalloc((void **)&d_units, unit_cap * sizeof(semz_unit)));
             HIPCHK(c, hipMalloc((void **)&d_res, unit_cap * sizeof(semz_result)));
         }
-        HIPCHK(c, hipMemcpyAsync(d_units, units.data(), n * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_units, units, n * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(d_res, 0xFF, n * sizeof(semz_result), c->stream));
         int rc = semz_decode_batch_device(c, units[0].kind, d_in, in_len, d_units, n, d_out + arena_base, arena_room, d_res);
         if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(res.data(), d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(res, d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    // One range of the batch on a helper device, in a thread of its own: upload of the range's bytes, the same
+    // kernels, results back in the frame of the batch (multi.h).  The output stays in the helper's arena.
+    int decode_on_helper(Helper &h, unsigned tag, const semz_unit *units, const MultiRange &r, uint64_t frame_base, semz_result *res)
+    {
+        semz_ctx *hc = h.c;
+        HIPCHK(hc, hipSetDevice(hc->device));
+        const size_t span = (size_t)(r.in_hi - r.in_lo);
+        if (span + 64 > h.in_cap) {
+            if (h.d_in) HIPCHK(hc, hipFree(h.d_in));
+            h.d_in = nullptr;
+            h.in_cap = span + 64;
+            HIPCHK(hc, hipMalloc((void **)&h.d_in, h.in_cap));
+        }
+        HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
+        if (r.out_room > (SIZE_MAX >> 2)) return RC_OOM;
+        if (h.out_used + r.out_room + 64 > h.out_cap) {
+            const size_t ncap = h.out_used + (size_t)r.out_room + 64;
+            uint8_t *nb = nullptr;
+            hipError_t e = hipMalloc((void **)&nb, ncap);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
+            HIPCHK(hc, e);
+            if (h.out_used) HIPCHK(hc, hipMemcpyAsync(nb, h.d_out, h.out_used, hipMemcpyDeviceToDevice, hc->stream));
+            HIPCHK(hc, hipStreamSynchronize(hc->stream));
+            if (h.d_out) HIPCHK(hc, hipFree(h.d_out));
+            h.d_out = nb;
+            h.out_cap = ncap;
+        }
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(units, r, local, clamped);
+        const size_t n = r.count;
+        if (n > h.unit_cap) {
+            if (h.d_units) HIPCHK(hc, hipFree(h.d_units));
+            if (h.d_res) HIPCHK(hc, hipFree(h.d_res));
+            h.d_units = nullptr; h.d_res = nullptr;
+            h.unit_cap = n + n / 2 + 16;
+            HIPCHK(hc, hipMalloc((void **)&h.d_units, h.unit_cap * sizeof(semz_unit)));
+            HIPCHK(hc, hipMalloc((void **)&h.d_res, h.unit_cap * sizeof(semz_result)));
+        }
+        HIPCHK(hc, hipMemcpyAsync(h.d_units, local.data(), n * sizeof(semz_unit), hipMemcpyHostToDevice, hc->stream));
+        HIPCHK(hc, hipMemsetAsync(h.d_res, 0xFF, n * sizeof(semz_result), hc->stream));
+        int rc = semz_decode_batch_device(hc, local[0].kind, h.d_in, span, h.d_units, n, h.d_out + h.out_used, (size_t)r.out_room, h.d_res);
+        if (rc) return rc;
+        std::vector<semz_result> lres(n);
+        HIPCHK(hc, hipMemcpyAsync(lres.data(), h.d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, hc->stream));
+        HIPCHK(hc, hipStreamSynchronize(hc->stream));
+        globalise_results(r, tag, h.out_used, frame_base, clamped, lres.data(), res, distrust.data());
+        h.out_used += (size_t)r.out_room;
         return 0;
     }
     // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP.
@@ -152,22 +256,44 @@ struct Run {
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
         d_in = nullptr; d_units = nullptr; d_res = nullptr; unit_cap = 0;
+        for (auto &h : helpers) {
+            (void)hipSetDevice(h.c->device);
+            if (h.d_in) (void)hipFree(h.d_in);
+            if (h.d_units) (void)hipFree(h.d_units);
+            if (h.d_res) (void)hipFree(h.d_res);
+            h.d_in = nullptr; h.d_units = nullptr; h.d_res = nullptr; h.unit_cap = 0; h.in_cap = 0;
+        }
+        if (!helpers.empty()) (void)hipSetDevice(c->device);
         in = nullptr;                          // no host pointer is kept beyond the call
     }
     // bytes [off, off + len) of the decoded stream into dst (host memory)
     int read(uint64_t off, uint8_t *dst, uint64_t len)
     {
         if (off > emitted || len > emitted - off) return semz_fail(c, -1, "semz_stream_read: range beyond the decoded stream");
+        std::vector<uint8_t> used(helpers.size(), 0);
         uint64_t at = 0;
         for (auto &sp : spans) {
             if (!len) break;
             if (off < at + sp.len) {
                 const uint64_t skip = off - at, take = std::min<uint64_t>(len, sp.len - skip);
-                HIPCHK(c, hipMemcpyAsync(dst, d_out + sp.off + skip, take, hipMemcpyDeviceToHost, c->stream));
+                const unsigned dev = multi_dev(sp.off);
+                if (dev == 0) HIPCHK(c, hipMemcpyAsync(dst, d_out + sp.off + skip, take, hipMemcpyDeviceToHost, c->stream));
+                else {
+                    Helper &h = helpers[dev - 1];
+                    HIPCHK(c, hipSetDevice(h.c->device));
+                    HIPCHK(c, hipMemcpyAsync(dst, h.d_out + multi_off(sp.off) + skip, take, hipMemcpyDeviceToHost, h.c->stream));
+                    used[dev - 1] = 1;
+                }
                 dst += take; off += take; len -= take;
             }
             at += sp.len;
         }
+        for (size_t i = 0; i < helpers.size(); i++)
+            if (used[i]) {
+                HIPCHK(c, hipSetDevice(helpers[i].c->device));
+                HIPCHK(c, hipStreamSynchronize(helpers[i].c->stream));
+            }
+        HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
@@ -237,7 +363,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                 rc = R.decode(units, res, R.out_used, total);
                 if (rc) { free(su); return rc; }
                 for (size_t i = 0; i < units.size(); i++) {
-                    if (res[i].status == SEMZ_E_OUT_CAP) continue;
+                    if (res[i].status == SEMZ_E_OUT_CAP || R.distrust[i]) continue;
                     res[i].out_off += R.out_used;
                     pre[units[i].in_off] = res[i];
                 }
@@ -289,7 +415,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                     rc = R.decode(units, res, R.out_used, total);
                     if (rc) return rc;
                     for (size_t i = 0; i < units.size(); i++) {
-                        if (res[i].status == SEMZ_E_OUT_CAP) continue;        // the hypothesis did not hold
+                        if (res[i].status == SEMZ_E_OUT_CAP || R.distrust[i]) continue;        // the hypothesis did not hold
                         res[i].out_off += R.out_used;
                         pre[units[i].in_off] = res[i];
                     }
@@ -362,8 +488,10 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
         guess = sat_mul(guess, 4);                                // RLE1 can expand far beyond the block size
     }
     for (size_t i = 0; i < units.size(); i++) {
+        if (R.distrust[i]) continue;                              // (decoded from a cut span on another device: see multi.h)
         by_bit[start_bits[i]] = i;
-        if (res[i].status == SEMZ_OK) R.out_used = arena0 + res[i].out_off + res[i].out_len > R.out_used ? arena0 + res[i].out_off + res[i].out_len : R.out_used;
+        const uint64_t end = arena0 + res[i].out_off + res[i].out_len;
+        if (res[i].status == SEMZ_OK && multi_dev(arena0 + res[i].out_off) == 0 && end > R.out_used) R.out_used = end;
     }
     // forward walk (bzip2.lisp:425-503)
     uint64_t pos = 0;
@@ -447,6 +575,7 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
                 rc = R.decode(units, res, R.out_used, si.total_out);
                 if (rc) { free(su); return rc; }
                 for (size_t i = 0; i < sn; i++) {
+                    if (R.distrust[i]) continue;
                     res[i].out_off += R.out_used;
                     pre[units[i].in_off] = std::make_pair(units[i], res[i]);
                 }

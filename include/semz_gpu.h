@@ -126,6 +126,17 @@ typedef struct semz_ctx semz_ctx;
 /* Opens the engine on one GPU (one context per process per GPU; calls on one
  * context must not overlap).  device = HIP device ordinal. */
 int semz_open(int device, semz_ctx **ctx);
+/* One input, several GPUs, inside the C call (the reference has no counterpart, its unit of
+ * parallelism is the caller's thread): devices[0] is the primary device and behaves as a context from semz_open;
+ * the stream calls (semz_decode_stream, semz_decode_stream_into, semz_stream_decode / read / release) split the
+ * input once on the host, cut the predicted batch into contiguous ranges of about equal compressed size, decode
+ * every range on its own device from the bytes of that range only (one host thread and one HIP stream per device,
+ * no data-path collective) and walk the merged results in the reference's order.  Units the walk has to decode
+ * on demand, and a failed unit whose input span was cut at a range boundary, are decoded on the primary device,
+ * which holds the whole input.  The batch calls (semz_decode_batch*) use the primary device only.  A device may be
+ * named more than once (two contexts on one GPU).  semz_close closes all of them. */
+int semz_open_multi(const int *devices, int ndev, semz_ctx **ctx);
+int semz_device_count(const semz_ctx *ctx);        /* 1 for semz_open, ndev for semz_open_multi */
 void semz_close(semz_ctx *ctx);
 const char *semz_last_error(const semz_ctx *ctx);
 

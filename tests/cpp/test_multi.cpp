@@ -1,0 +1,108 @@
+// CPU-side check of the multi-device partition / merge logic (decompress_amd/csrc/multi.h) with made-up
+// per-device results: no HIP, built with g++ by tests/test_multi_partition.py.
+#include <cassert>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../decompress_amd/csrc/multi.h"
+
+using namespace semz;
+
+static semz_unit unit(uint64_t in_off, uint64_t in_limit, uint64_t out_off, uint64_t out_cap)
+{
+    semz_unit u;
+    memset(&u, 0, sizeof u);
+    u.kind = SEMZ_UNIT_GZIP;
+    u.in_off = in_off; u.in_limit = in_limit; u.out_off = out_off; u.out_cap = out_cap;
+    return u;
+}
+
+// every device "decodes" its localised units: out_len = out_cap, out_off = where it was told to write (or a
+// running offset for SEMZ_OUT_AUTO), in_end_bit = 8 * (local in_off + 10); a unit cut short fails when told to
+static std::vector<semz_result> fake_device(const std::vector<semz_unit> &local, const std::vector<uint8_t> &clamped, bool fail_cut)
+{
+    std::vector<semz_result> r(local.size());
+    uint64_t auto_off = 0;
+    for (size_t i = 0; i < local.size(); i++) {
+        memset(&r[i], 0, sizeof r[i]);
+        r[i].status = fail_cut && clamped[i] ? SEMZ_EOF : SEMZ_OK;
+        r[i].out_len = local[i].out_cap ? local[i].out_cap : 1000;
+        if (local[i].out_off == SEMZ_OUT_AUTO) { r[i].out_off = auto_off; auto_off += r[i].out_len; }
+        else r[i].out_off = local[i].out_off;
+        r[i].in_end_bit = 8 * (local[i].in_off + 10);
+    }
+    return r;
+}
+
+static void check(size_t n, unsigned parts, bool fixed, bool fail_cut)
+{
+    const uint64_t in_len = 1000 * n + 77;
+    std::vector<semz_unit> u;
+    uint64_t out = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cap = 100 + 7 * (i % 13);
+        u.push_back(unit(1000 * i + (i % 3), in_len, fixed ? out : SEMZ_OUT_AUTO, fixed ? cap : 0));
+        out += cap;
+    }
+    const uint64_t frame_base = 4096;
+    auto ranges = partition_units(u.data(), n, in_len, parts, 64, 1000 * n);
+    assert(!ranges.empty() && ranges.size() <= parts);
+    // contiguous, complete, in order; byte-balanced within one unit
+    size_t at = 0;
+    for (auto &r : ranges) { assert(r.first == at && r.count > 0); at += r.count; }
+    assert(at == n);
+    if (ranges.size() == parts && n >= 4 * parts)
+        for (auto &r : ranges) assert(r.count + 2 >= n / parts && r.count <= n / parts + 2);
+    std::vector<semz_result> res(n);
+    std::vector<uint8_t> distrust(n, 0xAA);
+    for (size_t p = 0; p < ranges.size(); p++) {
+        const MultiRange &r = ranges[p];
+        assert(r.in_lo == u[r.first].in_off);
+        assert(r.in_hi <= in_len && r.in_hi > u[r.first + r.count - 1].in_off);
+        if (p + 1 < ranges.size()) assert(r.in_hi >= u[ranges[p + 1].first].in_off);       // the whole range is inside its bytes
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(u.data(), r, local, clamped);
+        for (size_t i = 0; i < r.count; i++) {
+            assert(local[i].in_off == u[r.first + i].in_off - r.in_lo);
+            assert(local[i].in_limit <= r.in_hi - r.in_lo && local[i].in_off <= local[i].in_limit);
+            assert(clamped[i] == (u[r.first + i].in_limit > r.in_hi));
+            if (fixed) assert(local[i].out_off + local[i].out_cap <= r.out_room);
+        }
+        auto lres = fake_device(local, clamped, fail_cut);
+        const uint64_t dev_base = 512 * p;                   // the device's arena had 512 p bytes in it already
+        globalise_results(r, (unsigned)p, dev_base, frame_base, clamped, lres.data(), res.data(), distrust.data());
+    }
+    // merged: input positions are global again, output offsets name device and place once the caller adds its base
+    for (size_t p = 0; p < ranges.size(); p++)
+        for (size_t i = ranges[p].first; i < ranges[p].first + ranges[p].count; i++) {
+            assert(res[i].in_end_bit == 8 * (u[i].in_off + 10));
+            const uint64_t off = res[i].out_off + (p ? frame_base : 0);
+            assert(multi_dev(off) == p);
+            if (fixed && p) assert(multi_off(off) == 512 * p + (u[i].out_off - ranges[p].out_lo));
+            if (fixed && !p) assert(off == u[i].out_off);
+            const bool cut = u[i].in_limit > ranges[p].in_hi;
+            assert(distrust[i] == (uint8_t)(fail_cut && cut));
+        }
+}
+
+int main()
+{
+    for (size_t n : {1, 2, 3, 7, 64, 1000})
+        for (unsigned parts : {1u, 2u, 3u, 8u})
+            for (int fixed = 0; fixed < 2; fixed++)
+                for (int fail = 0; fail < 2; fail++) check(n, parts, fixed != 0, fail != 0);
+    // units with a known end (xz blocks): a range's bytes reach to the end of its last unit
+    {
+        std::vector<semz_unit> u;
+        for (int i = 0; i < 10; i++) u.push_back(unit(100 * i, 100 * i + 130, 50 * i, 50));
+        auto r = partition_units(u.data(), u.size(), 5000, 2, 0, 0);
+        assert(r.size() == 2 && r[0].in_hi >= u[r[0].count - 1].in_limit);
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(u.data(), r[0], local, clamped);
+        for (auto c : clamped) assert(!c);
+    }
+    puts("multi partition / merge: ok");
+    return 0;
+}
