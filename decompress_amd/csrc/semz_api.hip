@@ -124,6 +124,8 @@ extern "C" void semz_close(semz_ctx *c)
     hipStreamSynchronize(c->stream);
     semz_profile_reset(c);
     for (auto &b : c->bufs) if (b.p) hipFree(b.p);
+    for (auto &b : c->pool) hipFree(b.p);
+    for (auto s : c->copy_streams) hipStreamDestroy(s);
     if (c->d_tabs) hipFree(c->d_tabs);
     hipStreamDestroy(c->stream);
     delete c;
@@ -154,6 +156,41 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
     if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
     if (!strcmp(name, "lzma-no-fast")) { c->lz_no_fast = value != 0; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
+}
+
+hipError_t semz_pool_take(semz_ctx *c, size_t bytes, void **p, size_t *cap)
+{
+    size_t best = SIZE_MAX;
+    for (size_t i = 0; i < c->pool.size(); i++)
+        if (c->pool[i].cap >= bytes && c->pool[i].cap / 2 <= bytes && (best == SIZE_MAX || c->pool[i].cap < c->pool[best].cap)) best = i;
+    if (best != SIZE_MAX) {
+        *p = c->pool[best].p;
+        *cap = c->pool[best].cap;
+        c->pool.erase(c->pool.begin() + best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && !c->pool.empty()) {          // what the pool holds may be what is missing
+        (void)hipGetLastError();
+        for (auto &b : c->pool) (void)hipFree(b.p);
+        c->pool.clear();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) *cap = bytes;
+    return e;
+}
+
+void semz_pool_give(semz_ctx *c, void *p, size_t cap)
+{
+    if (!p) return;
+    c->pool.push_back(semz_devbuf{p, cap});
+    if (c->pool.size() > SEMZ_POOL_MAX) {
+        size_t small = 0;
+        for (size_t i = 1; i < c->pool.size(); i++)
+            if (c->pool[i].cap < c->pool[small].cap) small = i;
+        (void)hipFree(c->pool[small].p);
+        c->pool.erase(c->pool.begin() + small);
+    }
 }
 
 // grow-only device scratch owned by the context

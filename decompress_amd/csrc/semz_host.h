@@ -34,6 +34,11 @@ struct semz_ctx {
     bool lz_no_fast = false;            // option "lzma-no-fast": general kernel only (A/B measurements, tests of the general kernel)
     // semz_open_multi: contexts on the other devices; the stream calls spread a predicted batch over all of them
     std::vector<semz_ctx *> helpers;
+    // Device buffers the stream calls have handed back (input copies, output arenas): a call that decodes a gigabyte
+    // should not pay hipMalloc and hipFree for it every time.  At most SEMZ_POOL_MAX buffers, the smallest goes first.
+    std::vector<semz_devbuf> pool;
+    // further streams for downloads of large results in parallel slices (created on first use)
+    std::vector<hipStream_t> copy_streams;
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};
@@ -51,6 +56,11 @@ int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...);
 void semz_span_begin(semz_ctx *c, const char *name);
 void semz_span_end(semz_ctx *c);
 int semz_scratch(semz_ctx *c, int slot, size_t bytes, void **p);
+constexpr size_t SEMZ_POOL_MAX = 4;
+// a device buffer of at least `bytes` (from the pool if one fits without wasting more than half); hipErrorOutOfMemory
+// comes back as such after the pool has been emptied and the allocation tried again
+hipError_t semz_pool_take(semz_ctx *c, size_t bytes, void **p, size_t *cap);
+void semz_pool_give(semz_ctx *c, void *p, size_t cap);
 
 extern "C" {
 void semz_build_check_tables(semz_check_tables *t);

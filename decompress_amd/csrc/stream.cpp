@@ -39,7 +39,8 @@ struct Run {
     semz_ctx *c;
     const uint8_t *in;
     size_t in_len;
-    uint8_t *d_in = nullptr;
+    uint8_t *d_in = nullptr;                   // (input copy and arena come from the context's pool and go back to it)
+    size_t d_in_cap = 0;
     uint8_t *d_out = nullptr;
     size_t out_cap = 0, out_used = 0;          // device output arena; decoded spans are appended
     semz_unit *d_units = nullptr;
@@ -62,17 +63,21 @@ struct Run {
     };
     std::vector<Helper> helpers;
     std::vector<uint8_t> distrust;             // per unit of the last decode(): the result must not be used (see multi.h)
+    std::vector<uint64_t> cand;                // gzip: member-start candidates found while the input was on its way up
+    bool cand_ready = false;
 
     ~Run()
     {
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
+        (void)hipStreamSynchronize(c->stream);
+        semz_pool_give(c, d_in, d_in_cap);
+        semz_pool_give(c, d_out, out_cap);
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
         for (auto &h : helpers) {
             (void)hipSetDevice(h.c->device);
-            if (h.d_in) (void)hipFree(h.d_in);
-            if (h.d_out) (void)hipFree(h.d_out);
+            (void)hipStreamSynchronize(h.c->stream);
+            semz_pool_give(h.c, h.d_in, h.in_cap);
+            semz_pool_give(h.c, h.d_out, h.out_cap);
             if (h.d_units) (void)hipFree(h.d_units);
             if (h.d_res) (void)hipFree(h.d_res);
         }
@@ -81,7 +86,7 @@ struct Run {
     int open()
     {
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipMalloc((void **)&d_in, in_len + 64));
+        HIPCHK(c, semz_pool_take(c, in_len + 64, (void **)&d_in, &d_in_cap));
         HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
         for (semz_ctx *hc : c->helpers) {
             Helper h;
@@ -99,19 +104,21 @@ struct Run {
     {
         if (need > (SIZE_MAX >> 2) || out_used > (SIZE_MAX >> 2)) return RC_OOM;      // the sums below cannot wrap
         if (out_used + need + 64 <= out_cap) return 0;
-        size_t ncap = (out_used + need + 64) * 3 / 2 + (1 << 20);
+        // the first request of a call is usually the whole prediction: no slack then (and the pool's buffer of the
+        // last call fits again); growth afterwards takes half as much again
+        size_t ncap = out_used ? (out_used + need + 64) * 3 / 2 + (1 << 20) : need + 64;
         uint8_t *n = nullptr;
-        hipError_t e = hipMalloc((void **)&n, ncap);
-        if (e == hipErrorOutOfMemory) {                        // without the slack, then
+        hipError_t e = semz_pool_take(c, ncap, (void **)&n, &ncap);
+        if (e == hipErrorOutOfMemory && out_used) {            // without the slack, then
             (void)hipGetLastError();
             ncap = out_used + need + 64;
-            e = hipMalloc((void **)&n, ncap);
+            e = semz_pool_take(c, ncap, (void **)&n, &ncap);
         }
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
         HIPCHK(c, e);
         if (out_used) HIPCHK(c, hipMemcpyAsync(n, d_out, out_used, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (d_out) HIPCHK(c, hipFree(d_out));
+        semz_pool_give(c, d_out, out_cap);
         d_out = n;
         out_cap = ncap;
         return 0;
@@ -176,22 +183,22 @@ struct Run {
         HIPCHK(hc, hipSetDevice(hc->device));
         const size_t span = (size_t)(r.in_hi - r.in_lo);
         if (span + 64 > h.in_cap) {
-            if (h.d_in) HIPCHK(hc, hipFree(h.d_in));
+            semz_pool_give(hc, h.d_in, h.in_cap);
             h.d_in = nullptr;
-            h.in_cap = span + 64;
-            HIPCHK(hc, hipMalloc((void **)&h.d_in, h.in_cap));
+            h.in_cap = 0;
+            HIPCHK(hc, semz_pool_take(hc, span + 64, (void **)&h.d_in, &h.in_cap));
         }
         HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
         if (r.out_room > (SIZE_MAX >> 2)) return RC_OOM;
         if (h.out_used + r.out_room + 64 > h.out_cap) {
-            const size_t ncap = h.out_used + (size_t)r.out_room + 64;
+            size_t ncap = h.out_used + (size_t)r.out_room + 64;
             uint8_t *nb = nullptr;
-            hipError_t e = hipMalloc((void **)&nb, ncap);
+            hipError_t e = semz_pool_take(hc, ncap, (void **)&nb, &ncap);
             if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
             HIPCHK(hc, e);
             if (h.out_used) HIPCHK(hc, hipMemcpyAsync(nb, h.d_out, h.out_used, hipMemcpyDeviceToDevice, hc->stream));
             HIPCHK(hc, hipStreamSynchronize(hc->stream));
-            if (h.d_out) HIPCHK(hc, hipFree(h.d_out));
+            semz_pool_give(hc, h.d_out, h.out_cap);
             h.d_out = nb;
             h.out_cap = ncap;
         }
@@ -252,19 +259,58 @@ struct Run {
     // what only the decode needs: the input copy and the unit tables (the arena stays for semz_stream_read)
     void drop_working_set()
     {
-        if (d_in) (void)hipFree(d_in);
+        (void)hipStreamSynchronize(c->stream);
+        semz_pool_give(c, d_in, d_in_cap);
+        d_in_cap = 0;
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
         d_in = nullptr; d_units = nullptr; d_res = nullptr; unit_cap = 0;
         for (auto &h : helpers) {
             (void)hipSetDevice(h.c->device);
-            if (h.d_in) (void)hipFree(h.d_in);
+            (void)hipStreamSynchronize(h.c->stream);
+            semz_pool_give(h.c, h.d_in, h.in_cap);
             if (h.d_units) (void)hipFree(h.d_units);
             if (h.d_res) (void)hipFree(h.d_res);
             h.d_in = nullptr; h.d_units = nullptr; h.d_res = nullptr; h.unit_cap = 0; h.in_cap = 0;
         }
         if (!helpers.empty()) (void)hipSetDevice(c->device);
         in = nullptr;                          // no host pointer is kept beyond the call
+    }
+    // Device to host.  A copy into pageable memory is staged by the runtime on the calling thread and runs at the
+    // speed of that thread's memcpy (17 GB/s here); a large one is therefore cut into slices that go side by side,
+    // each on a thread and a stream of its own (the device that `x` belongs to is current).
+    static int download(semz_ctx *x, uint8_t *dst, const uint8_t *src, uint64_t len)
+    {
+        constexpr uint64_t SLICE_MIN = 16u << 20;
+        constexpr unsigned SLICES = 4;
+        if (len < 2 * SLICE_MIN) {
+            HIPCHK(x, hipMemcpyAsync(dst, src, len, hipMemcpyDeviceToHost, x->stream));
+            return 0;
+        }
+        HIPCHK(x, hipStreamSynchronize(x->stream));            // what is copied was written on this stream
+        while (x->copy_streams.size() < SLICES) {
+            hipStream_t st;
+            HIPCHK(x, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            x->copy_streams.push_back(st);
+        }
+        const uint64_t per = ((len / SLICES) + 4095) & ~4095ull;
+        hipError_t errs[SLICES];
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < SLICES; t++) {
+            const uint64_t o = std::min<uint64_t>(len, per * t), n = std::min<uint64_t>(len - o, per);
+            errs[t] = hipSuccess;
+            if (!n) continue;
+            th.emplace_back([=, &errs] {
+                hipError_t e = hipSetDevice(x->device);
+                if (e == hipSuccess) e = hipMemcpyAsync(dst + o, src + o, n, hipMemcpyDeviceToHost, x->copy_streams[t]);
+                if (e == hipSuccess) e = hipStreamSynchronize(x->copy_streams[t]);
+                errs[t] = e;
+            });
+        }
+        for (auto &t : th) t.join();
+        for (unsigned t = 0; t < SLICES; t++)
+            if (errs[t] != hipSuccess) return semz_fail(x, -2, "download: %s", hipGetErrorString(errs[t]));
+        return 0;
     }
     // bytes [off, off + len) of the decoded stream into dst (host memory)
     int read(uint64_t off, uint8_t *dst, uint64_t len)
@@ -277,11 +323,14 @@ struct Run {
             if (off < at + sp.len) {
                 const uint64_t skip = off - at, take = std::min<uint64_t>(len, sp.len - skip);
                 const unsigned dev = multi_dev(sp.off);
-                if (dev == 0) HIPCHK(c, hipMemcpyAsync(dst, d_out + sp.off + skip, take, hipMemcpyDeviceToHost, c->stream));
-                else {
+                if (dev == 0) {
+                    int rc = download(c, dst, d_out + sp.off + skip, take);
+                    if (rc) return rc;
+                } else {
                     Helper &h = helpers[dev - 1];
                     HIPCHK(c, hipSetDevice(h.c->device));
-                    HIPCHK(c, hipMemcpyAsync(dst, h.d_out + multi_off(sp.off) + skip, take, hipMemcpyDeviceToHost, h.c->stream));
+                    int rc = download(h.c, dst, h.d_out + multi_off(sp.off) + skip, take);
+                    if (rc) return semz_fail(c, rc, "device %d: %s", h.c->device, h.c->err);
                     used[dev - 1] = 1;
                 }
                 dst += take; off += take; len -= take;
@@ -331,6 +380,38 @@ inline uint64_t sat_add(uint64_t a, uint64_t b) { uint64_t r; return __builtin_a
 inline uint64_t deflate_bound(uint64_t rem) { return sat_add(sat_mul(rem, 1032), 1024); }     // 258 bytes per two bits
 inline uint64_t lzma_bound(uint64_t rem) { return sat_add(sat_mul(rem, 1ull << 18), 1 << 21); } // 2 MiB per 11-byte LZMA2 chunk
 
+// Places that look like the start of a gzip member: 1F 8B 08, reserved flag bits clear, XFL one of the values
+// deflate writers use (0, 2, 4) and OS a value RFC 1952 lists (0..13, 255).  They are hypotheses only (see
+// run_deflate_family), so the test may be as strict as it likes: a member it misses is decoded by the walk,
+// alone; a look-alike it lets through costs the member around it the same.  Ten bytes must match where three
+// did, and look-alikes inside compressed data drop from a few per gigabyte to none in a thousand.  The scan is
+// cut into pieces for four threads (memchr runs at the speed of one core's loads).
+std::vector<uint64_t> scan_gzip_candidates(const uint8_t *in, uint64_t in_len)
+{
+    std::vector<uint64_t> all;
+    if (in_len < 18) return all;
+    const uint64_t last = in_len - 18;                            // last position a member can start at
+    const unsigned parts = in_len >= (8u << 20) ? 4 : 1;
+    std::vector<std::vector<uint64_t>> found(parts);
+    auto scan = [&](unsigned t) {
+        const uint64_t lo = (last + 1) / parts * t, hi = t + 1 == parts ? last + 1 : (last + 1) / parts * (t + 1);
+        for (uint64_t p = lo; p < hi; p++) {
+            const void *hit = memchr(in + p, 0x1F, hi - p);
+            if (!hit) break;
+            p = (uint64_t)((const uint8_t *)hit - in);
+            if (in[p + 1] == 0x8B && in[p + 2] == 8 && in[p + 3] < 0x20 && (in[p + 8] == 0 || in[p + 8] == 2 || in[p + 8] == 4) &&
+                (in[p + 9] <= 13 || in[p + 9] == 255))
+                found[t].push_back(p);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < parts; t++) th.emplace_back(scan, t);
+    scan(0);
+    for (auto &t : th) t.join();
+    for (auto &f : found) all.insert(all.end(), f.begin(), f.end());
+    return all;
+}
+
 // ---- deflate / zlib / gzip ----
 int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stream_info *info)
 {
@@ -379,14 +460,11 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
             // which sizes its output span.  The forward walk below (interface.lisp:91-133) only uses the result
             // of a candidate it actually reaches, and only if its span was large enough; everything else (a
             // look-alike inside compressed data, a member followed by one) is decoded again, alone.
-            std::vector<uint64_t> cand;
+            const bool trace = getenv("SEMZ_TRACE") != nullptr;
+            auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+            const double tr0 = now();
             const uint8_t *in = R.in;
-            for (uint64_t p = 0; p + 18 <= R.in_len; p++) {
-                const void *hit = memchr(in + p, 0x1F, R.in_len - 17 - p);
-                if (!hit) break;
-                p = (uint64_t)((const uint8_t *)hit - in);
-                if (in[p + 1] == 0x8B && in[p + 2] == 8 && in[p + 3] < 0x20) cand.push_back(p);
-            }
+            std::vector<uint64_t> cand = R.cand_ready ? std::move(R.cand) : scan_gzip_candidates(in, R.in_len);
             if (cand.size() >= 2 && cand[0] == 0) {
                 std::vector<semz_unit> units;
                 uint64_t total = 0;
@@ -408,12 +486,15 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                 }
                 // (look-alike headers in a large single member can hypothesise gigabytes each: speculation is only
                 // worth a bounded amount of memory, otherwise the members are decoded one after the other)
+                const double tr1 = now();
                 int rc = units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len) ? R.reserve(total) : Run::RC_OOM;
                 if (rc && rc != Run::RC_OOM) return rc;
+                const double tr2 = now();
                 if (rc == 0) {
                     std::vector<semz_result> res;
                     rc = R.decode(units, res, R.out_used, total);
                     if (rc) return rc;
+                    if (trace) fprintf(stderr, "gzip members: candidates %.1f ms (%zu), arena %.1f ms, upload wait + decode %.1f ms\n", tr1 - tr0, cand.size(), tr2 - tr1, now() - tr2);
                     for (size_t i = 0; i < units.size(); i++) {
                         if (res[i].status == SEMZ_E_OUT_CAP || R.distrust[i]) continue;        // the hypothesis did not hold
                         res[i].out_off += R.out_used;
@@ -424,6 +505,11 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
             }
         }
     }
+    const double tw0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    struct WalkTrace {
+        double t0;
+        ~WalkTrace() { if (getenv("SEMZ_TRACE")) fprintf(stderr, "gzip members: walk %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0); }
+    } walk_trace{tw0};
     uint64_t pos = 0;
     for (uint32_t member = 0;; member++) {
         semz_result r;
@@ -830,7 +916,15 @@ extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_
     const double t0 = now();
     semz_decoded *Rp = new semz_decoded{Run{c, in, in_len}};
     Run &R = Rp->run;
+    // (the upload from pageable memory keeps this thread busy: the scan for gzip member starts runs beside it)
+    std::thread scanner;
+    if (fmt == SEMZ_FMT_GZIP && all_members && in_len >= (1u << 20))
+        scanner = std::thread([&R, in, in_len] { R.cand = scan_gzip_candidates(in, in_len); });
     int rc = R.open();
+    if (scanner.joinable()) {
+        scanner.join();
+        R.cand_ready = true;
+    }
     if (rc) { delete Rp; return rc; }
     const double t1 = now();
     Outcome oc;
@@ -855,8 +949,9 @@ extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_
     default: rc = semz_fail(c, -1, "format %d has no stream decoder", fmt); break;
     }
     if (rc) { delete Rp; return rc; }
+    const double t2 = now();
     R.drop_working_set();
-    if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms\n", t1 - t0, now() - t1);
+    if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms, drop %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
     res->status = oc.status;
     res->detail = oc.detail;
     res->in_end_bit = 8 * oc.consumed;

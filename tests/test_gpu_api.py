@@ -190,3 +190,24 @@ def test_decode_stream_into_caller_buffer():
     small = ctypes.create_string_buffer(len(want) - 1)
     rc, n, res, _ = eng.decode_stream_into(_lib.FMT_GZIP, data, small, True)
     assert (rc, n, res.status) == (1, len(want), 0) and small.raw == b"\0" * (len(want) - 1)
+
+
+def test_damaged_member_late_in_a_large_stream_delivers_everything_before_it():
+    """A stream large enough for the sliced download (4 x 16 MiB and more): the members in front of a damaged one
+    arrive byte-exact in the caller's buffer, the status is the damaged member's, nothing is written behind."""
+    import ctypes
+    import gzip
+    from decompress_amd import _lib
+    parts = [corpus.text(2 << 20, seed=900 + i) for i in range(40)]
+    members = [gzip.compress(p, 1) for p in parts]
+    bad = bytearray(b"".join(members))
+    k = 29                                                            # in the third quarter
+    bad[sum(len(m) for m in members[:k]) + len(members[k]) // 2] ^= 0x04
+    want = b"".join(parts[:k])
+    eng = api._get_engine()
+    buf = ctypes.create_string_buffer(len(b"".join(parts)) + 64)
+    rc, n, res, info = eng.decode_stream_into(_lib.FMT_GZIP, bytes(bad), buf, True)
+    assert rc == 0 and res.status != 0 and info.nmembers == k and n == len(want)
+    assert buf.raw[:n] == want and buf.raw[n:n + 64] == b"\0" * 64
+    good, res2, info2 = eng.decode_stream(_lib.FMT_GZIP, b"".join(members), True)
+    assert res2.status == 0 and info2.nmembers == 40 and good == b"".join(parts)
