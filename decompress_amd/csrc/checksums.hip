@@ -107,8 +107,6 @@ __device__ __forceinline__ Seg lane_segment(uint64_t n, uint32_t a, int lane)
     return g;
 }
 
-__device__ void sha256_unit(const uint8_t *p, uint64_t n, uint32_t digest_le_words[8]);
-
 constexpr int CK_WAVES = 4;
 
 __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *out, const semz_unit *units,
@@ -223,7 +221,10 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
         check[0] = (uint32_t)((S2 << 16) | S1);
         check_len = 4;
     } else if (t.check_kind == SEMZ_TK_SHA256) {
-        if (lane == 0) sha256_unit(p, n, check);
+        // computed by sha256_kernel, launched in front of this one: it left the digest in the result
+        for (int k = 0; k < 8; k++)
+            check[k] = (uint32_t)r.check[4 * k] | (uint32_t)r.check[4 * k + 1] << 8 | (uint32_t)r.check[4 * k + 2] << 16 |
+                       (uint32_t)r.check[4 * k + 3] << 24;
         check_len = 32;
     }
 
@@ -264,7 +265,13 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
     }
 }
 
-// SHA-256 (RFC 6234), one lane: sha256.lisp:27-164; constants tables.lisp:152-197
+// SHA-256 (RFC 6234): sha256.lisp:27-164; constants tables.lisp:152-197.
+// A unit's digest is one serial chain of compressions (16,384 for a 1 MiB block), so a unit is one wave and the
+// chain is kept as short as it can be: the message schedule does not belong to it.  Per pass of 64 message blocks,
+// lane b loads block b (a 64-byte line), expands it to the 64 schedule words, adds the round constants and leaves
+// them in LDS; then all lanes run the 64 x 64 rounds on the same values (sixteen vector instructions a round,
+// the W + K words coming as LDS broadcasts, four at a time).  One lane doing everything took 254 ms for 2048
+// blocks of 1 MiB, 42 % of config 4.
 __constant__ uint32_t K256[64] = {
     0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,
     0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
@@ -275,55 +282,99 @@ __constant__ uint32_t K256[64] = {
     0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,
     0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
 
-__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
 
-__device__ void sha256_block(uint32_t h[8], const uint32_t wi[16])
+constexpr int SHA_STRIDE = 68;                 // words per block in LDS: 64 and a pad that keeps 16-byte alignment
+
+__global__ __launch_bounds__(64) void sha256_kernel(const uint8_t *out, uint32_t nunits, semz_result *results, const semz_tail *tails)
 {
-    uint32_t w[16];
+    __shared__ __align__(16) uint32_t wk[64 * SHA_STRIDE];
+    const uint32_t u = blockIdx.x, lane = threadIdx.x;
+    if (u >= nunits) return;
+    if (results[u].status != SEMZ_OK || tails[u].check_kind != SEMZ_TK_SHA256) return;
+    const uint8_t *p = out + results[u].out_off;
+    const uint64_t n = results[u].out_len;
+    const uint64_t nblocks = (n + 9 + 63) / 64;                    // data, 0x80, zeros, 64-bit length
+    uint32_t h0 = 0x6a09e667, h1 = 0xbb67ae85, h2 = 0x3c6ef372, h3 = 0xa54ff53a, h4 = 0x510e527f, h5 = 0x9b05688c,
+             h6 = 0x1f83d9ab, h7 = 0x5be0cd19;
+    for (uint64_t b0 = 0; b0 < nblocks; b0 += 64) {
+        const uint64_t j = b0 + lane;
+        const uint32_t nb = nblocks - b0 < 64 ? (uint32_t)(nblocks - b0) : 64u;
+        if (lane < nb) {
+            uint32_t w[16];
+            if (64 * j + 64 <= n) {
+                uint4 q[4];
+                __builtin_memcpy(q, p + 64 * j, 64);
 #pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = wi[i];
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+                for (int k = 0; k < 4; k++) {
+                    w[4 * k] = __builtin_bswap32(q[k].x); w[4 * k + 1] = __builtin_bswap32(q[k].y);
+                    w[4 * k + 2] = __builtin_bswap32(q[k].z); w[4 * k + 3] = __builtin_bswap32(q[k].w);
+                }
+            } else {
+                // one of the last two blocks: the rest of the data, the 0x80, zeros, and the bit count at the very end
 #pragma unroll
-    for (int i = 0; i < 64; i++) {
-        if (i >= 16) {
-            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
-            uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
-            w[i & 15] = s1 + w[(i - 7) & 15] + s0 + w[i & 15];
+                for (int k = 0; k < 16; k++) {
+                    uint32_t x = 0;
+                    for (int q = 0; q < 4; q++) {
+                        const uint64_t at = 64 * j + 4 * k + q;
+                        const uint32_t byte = at < n ? p[at] : at == n ? 0x80u : 0u;
+                        x = (x << 8) | byte;
+                    }
+                    w[k] = x;
+                }
+                if (j + 1 == nblocks) { w[14] = (uint32_t)((n * 8) >> 32); w[15] = (uint32_t)(n * 8); }
+            }
+            uint32_t *dst = wk + lane * SHA_STRIDE;
+#pragma unroll
+            for (int t = 0; t < 64; t++) {
+                if (t >= 16) {
+                    const uint32_t w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                    const uint32_t s0 = rotr(w15, 7) ^ rotr(w15, 18) ^ (w15 >> 3);
+                    const uint32_t s1 = rotr(w2, 17) ^ rotr(w2, 19) ^ (w2 >> 10);
+                    w[t & 15] = s1 + w[(t - 7) & 15] + s0 + w[t & 15];
+                }
+                dst[t] = w[t & 15] + K256[t];
+            }
         }
-        uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K256[i] + w[i & 15];
-        uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
-
-__device__ void sha256_unit(const uint8_t *p, uint64_t n, uint32_t digest_le_words[8])
-{
-    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    uint32_t w[16];
-    uint64_t i = 0;
-    for (; i + 64 <= n; i += 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // the chain: every lane computes the same values
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(wk + b * SHA_STRIDE);
+            uint32_t a = h0, bb = h1, c = h2, d = h3, e = h4, f = h5, g = h6, hh = h7;
+            // (the values are the same in every lane and the compiler knows it: left alone it moves the chain to
+            // the scalar unit, which has no rotate, and pays a v_alignbit + v_readfirstlane round trip for each;
+            // the empty asm statements pin the chain to the vector pipe)
+            asm volatile("" : "+v"(a), "+v"(bb), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(hh));
 #pragma unroll
-        for (int k = 0; k < 16; k++) w[k] = __builtin_bswap32(ld_u32(p + i + 4 * k));
-        sha256_block(h, w);
+            for (int t4 = 0; t4 < 16; t4++) {
+                uint4 x = src[t4];
+                asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+                const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) | (~e & g)) + xs[q];
+                    const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & bb) | (c & (a | bb)));
+                    hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+                }
+            }
+            h0 += a; h1 += bb; h2 += c; h3 += d; h4 += e; h5 += f; h6 += g; h7 += hh;
+            asm volatile("" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "+v"(h4), "+v"(h5), "+v"(h6), "+v"(h7));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    uint8_t tail[128];
-    uint32_t r = (uint32_t)(n - i);
-    for (int k = 0; k < 128; k++) tail[k] = 0;
-    for (uint32_t k = 0; k < r; k++) tail[k] = p[i + k];
-    tail[r] = 0x80;
-    uint32_t tl = (r + 9 <= 64) ? 64 : 128;
-    uint64_t bits = n * 8;
-    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
-    for (uint32_t o = 0; o < tl; o += 64) {
-        for (int k = 0; k < 16; k++)
-            w[k] = ((uint32_t)tail[o + 4 * k] << 24) | ((uint32_t)tail[o + 4 * k + 1] << 16) |
-                   ((uint32_t)tail[o + 4 * k + 2] << 8) | tail[o + 4 * k + 3];
-        sha256_block(h, w);
+    if (lane == 0) {
+        // digest bytes = big-endian words (sha256.lisp:159-164)
+        const uint32_t hw[8] = {h0, h1, h2, h3, h4, h5, h6, h7};
+        semz_result *r = results + u;
+        for (int k = 0; k < 8; k++) {
+            r->check[4 * k] = (uint8_t)(hw[k] >> 24); r->check[4 * k + 1] = (uint8_t)(hw[k] >> 16);
+            r->check[4 * k + 2] = (uint8_t)(hw[k] >> 8); r->check[4 * k + 3] = (uint8_t)hw[k];
+        }
     }
-    // digest bytes = big-endian words; as the little-endian words the reference compares (sha256.lisp:159-164)
-    for (int k = 0; k < 8; k++) digest_le_words[k] = __builtin_bswap32(h[k]);
 }
 
 } // namespace
@@ -333,6 +384,7 @@ extern "C" void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_un
                                      const semz_check_tables *d_tabs, uint32_t kind_mask, hipStream_t stream)
 {
     if (nunits == 0) return;
+    if (kind_mask & (1u << SEMZ_TK_SHA256)) sha256_kernel<<<nunits, 64, 0, stream>>>(d_out, nunits, d_results, d_tails);
     checksum_kernel<<<(nunits + CK_WAVES - 1) / CK_WAVES, 64 * CK_WAVES, 0, stream>>>(
         d_out, d_units, nunits, d_results, d_tails, d_tabs, kind_mask);
 }

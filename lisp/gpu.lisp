@@ -73,6 +73,7 @@
   (out-end :uint64))
 
 (cffi:defcfun ("semz_open" semz-open) :int (device :int) (ctx :pointer))
+(cffi:defcfun ("semz_open_multi" semz-open-multi) :int (devices :pointer) (ndev :int) (ctx :pointer))
 (cffi:defcfun ("semz_close" semz-close) :void (ctx :pointer))
 (cffi:defcfun ("semz_last_error" semz-last-error) :string (ctx :pointer))
 (cffi:defcfun ("semz_strerror" semz-strerror) :string (status :int))
@@ -98,7 +99,8 @@
 (defvar *enabled* t
   "When nil the :around methods step aside and the reference decodes everything.")
 (defvar *device* 0
-  "HIP device ordinal the engine opens.")
+  "HIP device ordinal the engine opens, or a list of ordinals: then one input is decoded on all of them
+(semz_open_multi; the first is the primary device).")
 (defvar *minimum-input-size* 65536
   "Inputs shorter than this many octets are decoded by the reference: a device call does not pay for them.")
 (defvar *chunk-size* (* 4 1024 1024)
@@ -119,10 +121,14 @@ signals `engine-error' (bind `*enabled*' to nil to use the reference's decoders)
       (progn
         (cffi:use-foreign-library libsemz-gpu)
         (cffi:with-foreign-object (p :pointer)
-          (let ((rc (semz-open *device* p)))
+          (let ((rc (if (listp *device*)
+                        (cffi:with-foreign-object (devs :int (length *device*))
+                          (loop for d in *device* for i from 0 do (setf (cffi:mem-aref devs :int i) d))
+                          (semz-open-multi devs (length *device*) p))
+                        (semz-open *device* p))))
             (unless (zerop rc)
               (error 'engine-error
-                     :message (format nil "semz_open(~d) failed with ~d (no usable MI355X?)" *device* rc))))
+                     :message (format nil "semz_open(~a) failed with ~d (no usable MI355X?)" *device* rc))))
           (setf *engine* (cffi:mem-ref p :pointer))))))
 
 (defun close-engine ()

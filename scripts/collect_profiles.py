@@ -14,7 +14,7 @@ import sys
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
-for fmt in ("gzip", "bzip2", "xz", "zlib"):
+for fmt in ("gzip", "bzip2", "xz", "xzsha", "zlib"):
     stats = os.path.join(src, f"{fmt}_kt_kernel_stats.csv")
     log = os.path.join(src, f"{fmt}_kt.log")
     if not os.path.exists(stats):
@@ -23,7 +23,8 @@ for fmt in ("gzip", "bzip2", "xz", "zlib"):
     line = [l for l in open(log) if l.startswith("{")][-1]
     d = json.loads(line)
     with open(os.path.join(prof, f"{tag}_{fmt}_kernel_stats.txt"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --format {fmt} "
+        args = {"xz": "xz --units 16 --replicate 8", "xzsha": "xz --check sha256 --units 16 --replicate 8"}.get(fmt, fmt)
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --format {args} "
                 f"--steps {d['steps']} --warmup {d['warmup']} --no-cpu --no-e2e --workers 1   (MI355X)\n")
         f.write(f"# workload: {d['config']['workload']}\n")
         f.write(f"{'kernel':34s} {'calls':>6s} {'total_ms':>10s} {'avg_ms':>9s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>6s}\n")

@@ -9,9 +9,16 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for F in gzip zlib bzip2 xz; do
-    timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${F}_kt -- \
-        python3 $R/bench.py --format $F --steps 5 --warmup 2 --no-cpu --no-e2e --workers 1 > $O/${F}_kt.log 2>&1
+# (xz: 16 distinct streams, each eight times, so that one process generates the corpus in the time allowed; the
+# block count and shape are those of the default run.  xzsha: the same with SHA-256 as the block check, BASELINE configs[3].)
+for F in gzip zlib bzip2 xz xzsha; do
+    case $F in
+        xz) ARGS="--format xz --units 16 --replicate 8" ;;
+        xzsha) ARGS="--format xz --check sha256 --units 16 --replicate 8" ;;
+        *) ARGS="--format $F" ;;
+    esac
+    timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o ${F}_kt -- \
+        python3 $R/bench.py $ARGS --steps 5 --warmup 2 --no-cpu --no-e2e --workers 1 > $O/${F}_kt.log 2>&1
     find $O -name "${F}_kt_kernel_stats.csv" -exec cp {} $O/ \; 2>/dev/null || true
     echo "$F done"
 done
