@@ -502,105 +502,125 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 if (dist_mode != MODE_LITONLY && endbits - P >= 64 + TOKEN_BITS) {
                     bool careful = false;
                     // 32-bit stand-ins for the loop conditions: bits to the end of the input (saturated), staged bits ahead
-                    uint32_t left = (uint32_t)(endbits - P < 0x7FFFFFFFull ? endbits - P : 0x7FFFFFFFull);
-                    uint32_t sleft = (uint32_t)(8 * s_hi - P);
-                    const bool round_ok = room >= (uint32_t)ROUND_BYTES && wsize >= 32768u;
+                    const uint32_t left = (uint32_t)(endbits - P < 0x7FFFFFFFull ? endbits - P : 0x7FFFFFFFull);
+                    const uint32_t sleft = (uint32_t)(8 * s_hi - P);
+                    // What decides whether a window is kept whole and whether another one follows is kept as four
+                    // countdowns that must all stay non-negative (one OR and one sign test), and the bit position
+                    // inside the loop as its low 32 bits (all the ring index looks at):
+                    //   c_tok  queue slots left after this window, minus one      c_byte  round bytes left, minus one
+                    //   c_left bits to the end of the input, minus 64 + TOKEN_BITS   c_stg  staged bits ahead, minus 256
+                    // `gate` has the sign bit set when windows cannot be kept whole at all in this round.
+                    int32_t c_tok = (int32_t)((uint32_t)QCAP - 1 - ntok), c_byte = (int32_t)((uint32_t)ROUND_BYTES - 1 - rbytes);
+                    int32_t c_left = (int32_t)(left - (64 + TOKEN_BITS)), c_stg = (int32_t)(sleft - 256);
+                    const uint32_t gate = room >= (uint32_t)ROUND_BYTES && wsize >= 32768u ? 0u : 0x80000000u;
+                    const bool short_history = avail < 32768u;
+                    uint32_t Pw = (uint32_t)P;
+                    const uint32_t Pw0 = Pw;
+                    // what the last window of the loop leaves for the code behind it
+                    uint32_t e, length, distance, ol, ooff, mrank, off;
+                    uint64_t litmask, stopmask, mask, matchmask;
+                    bool cut_window;                                           // the last window could not be kept whole
                     for (;;) {
-                    // ---- window decode: lane l takes the token that would start at bit P + l ----
-                    COUNT(0, 1);
-                    const uint32_t bp = (uint32_t)P + lane;                    // the ring index only needs the low bits
-                    const uint32_t sh = bp & 31;
-                    const uint32_t *wp = ring32 + ((bp >> 5) & (IN_RING / 4 - 1));
-                    const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-                    const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-                    const uint32_t e = L.lit_root[lo & ((1u << LIT_ROOT_BITS) - 1)];
-                    const uint32_t cl = e & 15;
-                    const uint32_t lx = (e >> 5) & 7;                          // 0 in literal entries
-                    const uint32_t length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(lo, cl, lx);
-                    const uint32_t o2 = cl + lx;                               // <= 20
-                    const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, o2);
-                    const uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
-                    const uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
-                    const uint32_t distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
-                    // Lane predicates are kept as 64-bit masks in scalar registers and combined there; lane_of() turns a
-                    // mask back into the predicate of a select or a branch without an instruction.
-                    const uint64_t litmask = __builtin_amdgcn_ballot_w64((e & LIT_FLAG) != 0);
-                    // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
-                    const uint64_t stopmask = __builtin_amdgcn_ballot_w64(cl == 0) | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
-                    const bool islit = lane_of(litmask);
-                    const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
-                    // the chain of token starts inside the window
-                    // The loop is four instructions per token, written out because the compiler has no way to branch
-                    // on the carry of a scalar add: `off` runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only
-                    // look at its low six bits), so the add carries out exactly when the chain leaves the window.
-                    // The s_nop is the wait state gfx950 wants between the VALU write of tbits and a v_readlane of it.
-                    uint64_t mask = 0;
-                    uint32_t offb = 0u - 64u, tlen;
-                    asm volatile("s_nop 0\n"
-                                 "1:\n\t"
-                                 "v_readlane_b32 %[t], %[tb], %[off]\n\t"
-                                 "s_bitset1_b64 %[m], %[off]\n\t"
-                                 "s_add_u32 %[off], %[off], %[t]\n\t"
-                                 "s_cbranch_scc0 1b"
-                                 : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen)
-                                 : [tb] "v"(tbits)
-                                 : "scc");
-                    const uint32_t off = offb + 64u;
-                    const uint64_t matchmask = mask & ~(stopmask | litmask);
-                    const uint32_t ol = lane_of(mask & ~stopmask) ? (islit ? 1u : length) : 0u;
-                    const uint32_t incl = wave_scan_add(ol);
-                    const uint32_t ooff = rbytes + incl - ol;                  // output offset inside the round
-                    const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
-                    {
+                        // ---- window decode: lane l takes the token that would start at bit P + l ----
+                        COUNT(0, 1);
+                        const uint32_t bp = Pw + lane;                         // the ring index only needs the low bits
+                        const uint32_t sh = bp & 31;
+                        const uint32_t *wp = ring32 + ((bp >> 5) & (IN_RING / 4 - 1));
+                        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+                        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                        e = L.lit_root[lo & ((1u << LIT_ROOT_BITS) - 1)];
+                        const uint32_t cl = e & 15;
+                        const uint32_t lx = (e >> 5) & 7;                      // 0 in literal entries
+                        length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(lo, cl, lx);
+                        const uint32_t o2 = cl + lx;                           // <= 20
+                        const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, o2);
+                        const uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
+                        const uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
+                        distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
+                        // Lane predicates are kept as 64-bit masks in scalar registers and combined there; lane_of() turns
+                        // a mask back into the predicate of a select or a branch without an instruction.
+                        litmask = __builtin_amdgcn_ballot_w64((e & LIT_FLAG) != 0);
+                        // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
+                        stopmask = __builtin_amdgcn_ballot_w64(cl == 0) | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
+                        const bool islit = lane_of(litmask);
+                        const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
+                        // the chain of token starts inside the window
+                        // The loop is four instructions per token, written out because the compiler has no way to branch
+                        // on the carry of a scalar add: `off` runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only
+                        // look at its low six bits), so the add carries out exactly when the chain leaves the window.
+                        // The s_nop is the wait state gfx950 wants between the VALU write of tbits and a v_readlane of it.
+                        mask = 0;
+                        uint32_t offb = 0u - 64u, tlen;
+                        asm volatile("s_nop 0\n"
+                                     "1:\n\t"
+                                     "v_readlane_b32 %[t], %[tb], %[off]\n\t"
+                                     "s_bitset1_b64 %[m], %[off]\n\t"
+                                     "s_add_u32 %[off], %[off], %[t]\n\t"
+                                     "s_cbranch_scc0 1b"
+                                     : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen)
+                                     : [tb] "v"(tbits)
+                                     : "scc");
+                        off = offb + 64u;
+                        matchmask = mask & ~(stopmask | litmask);
+                        // (a token of the chain that the scalar step has to take counts as more bytes than a round holds:
+                        // the window is then not kept whole without a test of its own, and offsets up to that token,
+                        // which is all that is used of such a window, are not affected)
+                        ol = lane_of(mask) ? (lane_of(stopmask) ? 2u * ROUND_BYTES : islit ? 1u : length) : 0u;
+                        const uint32_t incl = wave_scan_add(ol);
+                        // output offset inside the round: bytes of the round so far (ROUND_BYTES - 1 - c_byte) + what this
+                        // window puts in front of the lane's token; the uniform part is taken off on the vector side
+                        ooff = ((incl - ol) - (uint32_t)c_byte) + ((uint32_t)ROUND_BYTES - 1);
+                        mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
+                        const uint32_t qslot = (mrank - (uint32_t)c_tok) + ((uint32_t)QCAP - 1);   // queue slot of the lane's match
                         // the usual window: no token for the scalar step, everything fits the round: keep it whole
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         const uint32_t nm = (uint32_t)__builtin_popcountll(matchmask);
-                        // (all operands are far below 2^31: one sign test for both limits)
-                        bool whole = (stopmask & mask) == 0 && round_ok &&
-                                     (int32_t)(((uint32_t)ROUND_BYTES - (rbytes + total)) | ((uint32_t)QCAP - (ntok + nm))) >= 0;
-                        if (whole && avail < 32768u) whole = (__builtin_amdgcn_ballot_w64(distance > avail + ooff) & matchmask) == 0;
-                        if (whole) {
-                            if (lane_of(mask & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
-                            join_lanes();
-                            if (lane_of(matchmask)) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
-                            join_lanes();
-                            COUNT(1, (uint32_t)__builtin_popcountll(mask));
-                            rbytes += total;
-                            ntok += nm;
-                            P += off;
-                            left -= off;
-                            sleft -= off;
-                            // straight on to the next window while the round, the staged input and the input's end allow
-                            if ((int32_t)(((uint32_t)QCAP - 1 - ntok) | ((uint32_t)ROUND_BYTES - 1 - rbytes) |
-                                          (left - (64 + TOKEN_BITS)) | (sleft - 256)) >= 0) continue;
-                            break;
+                        // (all operands are far below 2^31: one sign test for all limits; c + 1 - n >= 0 says n fits)
+                        cut_window = true;
+                        if (__builtin_expect((int32_t)(((uint32_t)c_byte + 1 - total) | ((uint32_t)c_tok + 1 - nm) | gate) < 0, 0)) break;
+                        if (short_history && (__builtin_amdgcn_ballot_w64(distance > avail + ooff) & matchmask) != 0) break;
+                        if (lane_of(mask & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
+                        join_lanes();
+                        if (lane_of(matchmask)) L.queue[qslot] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                        join_lanes();
+                        COUNT(1, (uint32_t)__builtin_popcountll(mask));
+                        c_byte -= (int32_t)total;
+                        c_tok -= (int32_t)nm;
+                        Pw += off;
+                        c_left -= (int32_t)off;
+                        c_stg -= (int32_t)off;
+                        cut_window = false;
+                        // straight on to the next window while the round, the staged input and the input's end allow
+                        if (__builtin_expect((c_tok | c_byte | c_left | c_stg) < 0, 0)) break;
+                    }
+                    rbytes = (uint32_t)ROUND_BYTES - 1 - (uint32_t)c_byte;
+                    ntok = (uint32_t)QCAP - 1 - (uint32_t)c_tok;
+                    P += Pw - Pw0;
+                    if (cut_window) {
+                        const uint32_t have = avail + ooff;                    // deflate.lisp:329-331
+                        const uint64_t hardmask = mask & (stopmask | (matchmask & __builtin_amdgcn_ballot_w64(distance > (have < wsize ? have : wsize))) |
+                                                          __builtin_amdgcn_ballot_w64((uint64_t)ooff + ol > (uint64_t)room));
+                        const uint64_t softmask = mask & (__builtin_amdgcn_ballot_w64(ooff >= (uint32_t)ROUND_BYTES) |
+                                                          (matchmask & __builtin_amdgcn_ballot_w64(ntok + mrank >= (uint32_t)QCAP)));
+                        const uint64_t cutmask = hardmask | softmask;
+                        uint64_t keep = mask;
+                        uint32_t adv = off;
+                        if (cutmask) {
+                            const uint32_t c = (uint32_t)__builtin_ctzll(cutmask);
+                            keep = mask & ((1ull << c) - 1);
+                            adv = c;
+                            careful = (hardmask >> c) & 1;
+                            rbytes = (uint32_t)__builtin_amdgcn_readlane((int)ooff, (int)c);
+                        } else {
+                            rbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + ol), 63);
                         }
-                    }
-                    const uint32_t have = avail + ooff;                        // deflate.lisp:329-331
-                    const uint64_t hardmask = mask & (stopmask | (matchmask & __builtin_amdgcn_ballot_w64(distance > (have < wsize ? have : wsize))) |
-                                                      __builtin_amdgcn_ballot_w64((uint64_t)ooff + ol > (uint64_t)room));
-                    const uint64_t softmask = mask & (__builtin_amdgcn_ballot_w64(ooff >= (uint32_t)ROUND_BYTES) |
-                                                      (matchmask & __builtin_amdgcn_ballot_w64(ntok + mrank >= (uint32_t)QCAP)));
-                    const uint64_t cutmask = hardmask | softmask;
-                    uint64_t keep = mask;
-                    uint32_t adv = off;
-                    if (cutmask) {
-                        const uint32_t c = (uint32_t)__builtin_ctzll(cutmask);
-                        keep = mask & ((1ull << c) - 1);
-                        adv = c;
-                        careful = (hardmask >> c) & 1;
-                        rbytes = (uint32_t)__builtin_amdgcn_readlane((int)ooff, (int)c);
-                    } else {
-                        rbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + ol), 63);
-                    }
-                    if (lane_of(keep & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
-                    join_lanes();
-                    if (lane_of(keep & ~litmask)) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
-                    join_lanes();
-                    ntok += (uint32_t)__builtin_popcountll(matchmask & keep);
-                    COUNT(1, (uint32_t)__builtin_popcountll(keep));
-                    P += adv;
-                    break;
+                        if (lane_of(keep & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
+                        join_lanes();
+                        if (lane_of(keep & ~litmask)) L.queue[ntok + mrank] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                        join_lanes();
+                        ntok += (uint32_t)__builtin_popcountll(matchmask & keep);
+                        COUNT(1, (uint32_t)__builtin_popcountll(keep));
+                        P += adv;
                     }
                     // the scalar step may queue a match and write a literal: only inside the round's limits
                     if (!careful || ntok >= (uint32_t)QCAP || rbytes >= (uint32_t)ROUND_BYTES) continue;
