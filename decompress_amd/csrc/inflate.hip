@@ -108,6 +108,8 @@ struct __align__(16) UnitLds {
     TreeMeta lit, dist, clen;
 };
 static_assert(sizeof(UnitLds) <= 10240, "sixteen units per CU");
+static_assert(__builtin_offsetof(UnitLds, clen_root) % 8 == 0 &&
+              __builtin_offsetof(UnitLds, lit) - __builtin_offsetof(UnitLds, clen_root) >= 512, "64 dummy queue slots fit the table scratch");
 
 typedef const __attribute__((address_space(4))) uint32_t *k_u32p;   // scalar-load view of read-only memory
 
@@ -513,7 +515,9 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     int32_t c_tok = (int32_t)((uint32_t)QCAP - 1 - ntok), c_byte = (int32_t)((uint32_t)ROUND_BYTES - 1 - rbytes);
                     int32_t c_left = (int32_t)(left - (64 + TOKEN_BITS)), c_stg = (int32_t)(sleft - 256);
                     const uint32_t gate = room >= (uint32_t)ROUND_BYTES && wsize >= 32768u ? 0u : 0x80000000u;
-                    const bool short_history = avail < 32768u;
+                    // (history available in front of the round; once it covers the window the test cannot fail, and it is
+                    // made all the same: two vector instructions and an AND where a test of a flag costs three scalar ones)
+                    const uint32_t avail_sat = avail < 32768u ? avail : 0x40000000u;
                     uint32_t Pw = (uint32_t)P;
                     const uint32_t Pw0 = Pw;
                     // what the last window of the loop leaves for the code behind it
@@ -565,7 +569,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         // (a token of the chain that the scalar step has to take counts as more bytes than a round holds:
                         // the window is then not kept whole without a test of its own, and offsets up to that token,
                         // which is all that is used of such a window, are not affected)
-                        ol = lane_of(mask) ? (lane_of(stopmask) ? 2u * ROUND_BYTES : islit ? 1u : length) : 0u;
+                        {
+                            uint32_t t0 = islit ? 1u : length;                 // (three selects, no branch)
+                            t0 = lane_of(stopmask) ? 2u * ROUND_BYTES : t0;
+                            ol = lane_of(mask) ? t0 : 0u;
+                        }
                         const uint32_t incl = wave_scan_add(ol);
                         // output offset inside the round: bytes of the round so far (ROUND_BYTES - 1 - c_byte) + what this
                         // window puts in front of the lane's token; the uniform part is taken off on the vector side
@@ -578,10 +586,18 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         // (all operands are far below 2^31: one sign test for all limits; c + 1 - n >= 0 says n fits)
                         cut_window = true;
                         if (__builtin_expect((int32_t)(((uint32_t)c_byte + 1 - total) | ((uint32_t)c_tok + 1 - nm) | gate) < 0, 0)) break;
-                        if (short_history && (__builtin_amdgcn_ballot_w64(distance > avail + ooff) & matchmask) != 0) break;
-                        if (lane_of(mask & litmask)) L.ring[(rpos + ooff) & RING_MASK] = (uint8_t)(e >> 8);
-                        join_lanes();
-                        if (lane_of(matchmask)) L.queue[qslot] = make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
+                        if (__builtin_expect((__builtin_amdgcn_ballot_w64(distance > avail_sat + ooff) & matchmask) != 0, 0)) break;
+                        // (every lane stores: the ones without a literal into a byte of their own of `flags`, which only
+                        // the resolve step uses, and it clears them first.  A select on the vector side instead of an
+                        // exec mask set up and taken down on the scalar side, which is the side this loop is short of)
+                        reinterpret_cast<uint8_t *>(&L)[lane_of(mask & litmask) ? (rpos + ooff) & RING_MASK
+                                                                              : (uint32_t)__builtin_offsetof(UnitLds, flags) + lane] = (uint8_t)(e >> 8);
+                        // (the same for the queue: lanes without a match store into eight bytes of their own of the tables
+                        // that only the construction of the next block's trees uses: clen_root, lens, clens, flags)
+                        *reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(&L) +
+                                                   (lane_of(matchmask) ? (uint32_t)__builtin_offsetof(UnitLds, queue) + 8u * qslot
+                                                                       : (uint32_t)__builtin_offsetof(UnitLds, clen_root) + 8u * lane)) =
+                            make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
                         join_lanes();
                         COUNT(1, (uint32_t)__builtin_popcountll(mask));
                         c_byte -= (int32_t)total;
