@@ -580,13 +580,22 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         ooff = ((incl - ol) - (uint32_t)c_byte) + ((uint32_t)ROUND_BYTES - 1);
                         mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
                         const uint32_t qslot = (mrank - (uint32_t)c_tok) + ((uint32_t)QCAP - 1);   // queue slot of the lane's match
-                        // the usual window: no token for the scalar step, everything fits the round: keep it whole
+                        // the usual window: no token for the scalar step, everything fits the round with a byte and a
+                        // queue slot to spare: keep it whole.  The countdowns are taken down first (the results are
+                        // what the tests look at); a window that is not kept puts them back.
                         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                         const uint32_t nm = (uint32_t)__builtin_popcountll(matchmask);
-                        // (all operands are far below 2^31: one sign test for all limits; c + 1 - n >= 0 says n fits)
-                        cut_window = true;
-                        if (__builtin_expect((int32_t)(((uint32_t)c_byte + 1 - total) | ((uint32_t)c_tok + 1 - nm) | gate) < 0, 0)) break;
-                        if (__builtin_expect((__builtin_amdgcn_ballot_w64(distance > avail_sat + ooff) & matchmask) != 0, 0)) break;
+                        c_byte -= (int32_t)total;
+                        c_tok -= (int32_t)nm;
+                        // (all operands are far below 2^31: one sign test for all limits)
+                        const int32_t fits = c_byte | c_tok | (int32_t)gate;
+                        if (__builtin_expect(fits < 0, 0) ||
+                            __builtin_expect((__builtin_amdgcn_ballot_w64(distance > avail_sat + ooff) & matchmask) != 0, 0)) {
+                            c_byte += (int32_t)total;
+                            c_tok += (int32_t)nm;
+                            cut_window = true;
+                            break;
+                        }
                         // (every lane stores: the ones without a literal into a byte of their own of `flags`, which only
                         // the resolve step uses, and it clears them first.  A select on the vector side instead of an
                         // exec mask set up and taken down on the scalar side, which is the side this loop is short of)
@@ -600,14 +609,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                             make_uint2(T_MATCH | (length << 2) | (ooff << 16), distance);
                         join_lanes();
                         COUNT(1, (uint32_t)__builtin_popcountll(mask));
-                        c_byte -= (int32_t)total;
-                        c_tok -= (int32_t)nm;
                         Pw += off;
                         c_left -= (int32_t)off;
                         c_stg -= (int32_t)off;
-                        cut_window = false;
                         // straight on to the next window while the round, the staged input and the input's end allow
-                        if (__builtin_expect((c_tok | c_byte | c_left | c_stg) < 0, 0)) break;
+                        if (__builtin_expect((fits | c_left | c_stg) < 0, 0)) { cut_window = false; break; }
                     }
                     rbytes = (uint32_t)ROUND_BYTES - 1 - (uint32_t)c_byte;
                     ntok = (uint32_t)QCAP - 1 - (uint32_t)c_tok;
