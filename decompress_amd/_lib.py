@@ -58,7 +58,7 @@ _lib = None
 
 EXPORTS = [
     "semz_open", "semz_open_multi", "semz_device_count", "semz_close", "semz_last_error", "semz_strerror", "semz_decode_batch",
-    "semz_decode_batch_device", "semz_decode_batch_device_noalloc", "semz_set_option", "semz_sync", "semz_stream",
+    "semz_decode_batch_device", "semz_decode_batch_device_noalloc", "semz_set_option", "semz_get_option", "semz_sync", "semz_stream",
     "semz_dev_alloc", "semz_dev_free", "semz_dev_upload", "semz_dev_download",
     "semz_event_create", "semz_event_record", "semz_event_elapsed_ms", "semz_event_destroy",
     "semz_split", "semz_free", "semz_decode_stream",
@@ -92,6 +92,7 @@ def load():
     lib.semz_decode_batch_device.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp]
     lib.semz_decode_batch_device_noalloc.argtypes = lib.semz_decode_batch_device.argtypes
     lib.semz_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    lib.semz_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
     lib.semz_sync.argtypes = [vp]
     lib.semz_stream.argtypes = [vp]
     lib.semz_stream.restype = vp
@@ -168,6 +169,11 @@ class Engine:
 
     def set_option(self, name, value):
         self._chk(self.lib.semz_set_option(self.h, name.encode(), value))
+
+    def get_option(self, name):
+        v = C.c_long()
+        self._chk(self.lib.semz_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def decode_batch(self, data, units, out_cap):
         """Host-buffer batch decode. Returns (bytes-like output buffer, list of Result)."""

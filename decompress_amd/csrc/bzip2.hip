@@ -1280,6 +1280,12 @@ extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
 }
 #endif
 
+size_t semz_bzip2_scratch_per_block()
+{
+    return sizeof(bz_meta) + (size_t)BZ_STRIDE * 2 + BZ_STRIDE * sizeof(uint32_t) + BZ_TEMP_STRIDE + BZ_SEGS * sizeof(bz_seg) +
+           BZ_IDS * sizeof(bz_row) + 2 * sizeof(uint32_t);
+}
+
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails)
 {

@@ -76,6 +76,47 @@ inline std::vector<MultiRange> partition_units(const semz_unit *u, size_t n, siz
     return out;
 }
 
+// The batch loop: contiguous ranges again, but as many as it takes for every range to fit
+// `limit` bytes of device memory -- the range's input bytes, its output room and `unit_scratch` bytes per unit of
+// decoder scratch.  `out_need[i]` is the room unit i asks for (its span if fixed, an estimate if the device packs
+// the outputs).  A range holds at least one unit, whatever that unit costs.
+inline std::vector<MultiRange> window_units(const semz_unit *u, size_t n, size_t in_len, const uint64_t *out_need, uint64_t limit,
+                                            uint64_t margin, uint64_t unit_scratch)
+{
+    std::vector<MultiRange> out;
+    size_t at = 0;
+    while (at < n) {
+        MultiRange r{};
+        r.first = at;
+        r.in_lo = u[at].in_off;
+        r.fixed = u[at].out_off != SEMZ_OUT_AUTO;
+        uint64_t room = 0, a = ~0ull, b = 0, hi = 0;
+        size_t end = at;
+        while (end < n) {
+            uint64_t h = end + 1 < n ? u[end + 1].in_off : in_len;
+            if (u[end].in_limit < in_len && u[end].in_limit > h) h = u[end].in_limit;
+            if (h < hi) h = hi;
+            const uint64_t h_m = h + margin < in_len ? h + margin : in_len;
+            const uint64_t cost = (h_m - r.in_lo) + room + out_need[end] + (uint64_t)(end + 1 - at) * unit_scratch;
+            if (end > at && cost > limit) break;
+            hi = h;
+            room += out_need[end];
+            if (r.fixed) {
+                if (u[end].out_off < a) a = u[end].out_off;
+                if (u[end].out_off + u[end].out_cap > b) b = u[end].out_off + u[end].out_cap;
+            }
+            end++;
+        }
+        r.count = end - at;
+        r.in_hi = hi + margin < in_len ? hi + margin : in_len;
+        r.out_lo = r.fixed ? a : 0;
+        r.out_room = r.fixed ? b - a : room;
+        out.push_back(r);
+        at = end;
+    }
+    return out;
+}
+
 // A range's units in the frame of the device that decodes them: input offsets from in_lo, limits cut at in_hi,
 // fixed output offsets from out_lo.  `clamped[i]` says that unit i lost part of its input span.
 inline void localise_units(const semz_unit *u, const MultiRange &r, std::vector<semz_unit> &local, std::vector<uint8_t> &clamped)

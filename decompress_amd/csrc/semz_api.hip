@@ -120,6 +120,8 @@ extern "C" void semz_close(semz_ctx *c)
     if (!c) return;
     for (semz_ctx *h : c->helpers) semz_close(h);
     c->helpers.clear();
+    for (semz_ctx *h : c->lanes) semz_close(h);
+    c->lanes.clear();
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     semz_profile_reset(c);
@@ -137,6 +139,7 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
 {
     if (!c || !name) return -1;
     for (semz_ctx *h : c->helpers) (void)semz_set_option(h, name, value);      // the other devices of semz_open_multi follow
+    for (semz_ctx *h : c->lanes) (void)semz_set_option(h, name, value);        // and the lanes of the batch loop
     if (!strcmp(name, "profile")) { c->profile = value != 0; return 0; }
     if (!strcmp(name, "window-size")) {
         if (value < 0) return semz_fail(c, -1, "window-size must be an unsigned integer");   // check-type, lzma2.lisp:212
@@ -155,6 +158,22 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
     }
     if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
     if (!strcmp(name, "lzma-no-fast")) { c->lz_no_fast = value != 0; return 0; }
+    if (!strcmp(name, "batch-budget")) {
+        if (value < 0) return semz_fail(c, -1, "batch-budget must be a number of bytes (0 = automatic)");
+        c->batch_budget = (uint64_t)value;
+        return 0;
+    }
+    return semz_fail(c, -1, "unknown option %s", name);
+}
+
+extern "C" int semz_get_option(semz_ctx *c, const char *name, long *value)
+{
+    if (!c || !name || !value) return -1;
+    if (!strcmp(name, "batch-budget")) { *value = (long)c->batch_budget; return 0; }
+    if (!strcmp(name, "windows")) { *value = (long)c->last_windows; return 0; }
+    if (!strcmp(name, "moved")) { *value = (long)c->last_moved; return 0; }
+    if (!strcmp(name, "profile")) { *value = c->profile; return 0; }
+    if (!strcmp(name, "window-size")) { *value = (long)c->window_size; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);
 }
 

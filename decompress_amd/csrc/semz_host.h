@@ -37,6 +37,15 @@ struct semz_ctx {
     // Device buffers the stream calls have handed back (input copies, output arenas): a call that decodes a gigabyte
     // should not pay hipMalloc and hipFree for it every time.  At most SEMZ_POOL_MAX buffers, the smallest goes first.
     std::vector<semz_devbuf> pool;
+    // The batch loop of the stream calls (stream.cpp: decode_windowed): two further contexts on this device, opened
+    // on first use, so that one window of a large input uploads while another decodes and a third downloads.
+    std::vector<semz_ctx *> lanes;
+    // option "batch-budget": device bytes a predicted batch of a stream call may take (input, output, decoder
+    // scratch); a larger batch is decoded window by window into host memory.  0 = three quarters of what the
+    // device has free when the call starts.
+    uint64_t batch_budget = 0;
+    uint64_t last_windows = 0;          // windows the last stream call decoded (semz_get_option "windows")
+    uint64_t last_moved = 0;            // pieces of such windows the last read found out of place in the caller's buffer ("moved")
     // further streams for downloads of large results in parallel slices (created on first use)
     std::vector<hipStream_t> copy_streams;
     struct span { const char *name; hipEvent_t a, b; };
@@ -72,6 +81,8 @@ void semz_launch_checksum(const uint8_t *d_out, const semz_unit *d_units, uint32
 }
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails);
+// device scratch semz_run_bzip2 takes per block (the batch loop sizes its windows with it)
+size_t semz_bzip2_scratch_per_block();
 // the accept-only fast path for xz blocks / LZMA2 units (lzma2_fast.hip); what it leaves with the internal retry
 // status is decoded by the general kernels of lzma2.hip
 void semz_launch_lzma2_fast(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits, uint8_t *d_out,

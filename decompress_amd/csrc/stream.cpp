@@ -13,10 +13,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <sys/mman.h>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "container.h"
@@ -62,6 +64,25 @@ struct Run {
         size_t unit_cap = 0;
     };
     std::vector<Helper> helpers;
+    // The batch loop (interface.lisp:91-133, common.lisp:255-257: bounded memory, nothing
+    // delivered is lost before an error).  A predicted batch that does not fit `budget` bytes of device memory is
+    // decoded window by window (multi.h: window_units): every window uploads its own bytes of the input, decodes
+    // into a device arena of its own and goes down into host memory, on one of several lanes -- two contexts on
+    // the primary device and the helper devices -- so that the upload of one window, the kernels of another and
+    // the download of a third overlap.  Window w of a call lives in chunks[w]; results point there with device
+    // tag WINDOW_TAG and offset w << 40 | offset in the chunk.  A chunk is a piece of the caller's buffer when the
+    // call has one and the predicted layout is the stream's layout (semz_decode_stream_into: nothing is copied
+    // twice), else host memory of the Run.  The walk afterwards is the same: it takes what it reaches, decodes
+    // on demand what the prediction missed, and stops at the first error with everything before it delivered.
+    static constexpr unsigned WINDOW_TAG = 255;
+    static constexpr int WINDOW_SHIFT = 40;
+    struct HostChunk { uint8_t *p = nullptr; uint64_t len = 0; bool owned = false; };
+    std::vector<HostChunk> chunks;
+    std::vector<Helper> lanes;
+    uint8_t *sink = nullptr;                   // the caller's output buffer, if the call has one
+    size_t sink_cap = 0;
+    uint64_t budget = 0;                       // device bytes a predicted batch may take
+    size_t windows_run = 0;                    // (trace)
     std::vector<uint8_t> distrust;             // per unit of the last decode(): the result must not be used (see multi.h)
     std::vector<uint64_t> cand;                // gzip: member-start candidates found while the input was on its way up
     bool cand_ready = false;
@@ -81,18 +102,57 @@ struct Run {
             if (h.d_units) (void)hipFree(h.d_units);
             if (h.d_res) (void)hipFree(h.d_res);
         }
+        release_lanes();
         if (!helpers.empty()) (void)hipSetDevice(c->device);
+        for (auto &k : chunks)
+            if (k.owned) free(k.p);
+    }
+    void release_lanes()
+    {
+        for (auto &h : lanes) {
+            (void)hipSetDevice(h.c->device);
+            (void)hipStreamSynchronize(h.c->stream);
+            // (a lane of the primary device is a context of its own: its buffers go to the primary's pool, where
+            // the next call looks for them)
+            semz_ctx *pc = h.c->device == c->device ? c : h.c;
+            pool_give_locked(pc, h.d_in, h.in_cap);
+            pool_give_locked(pc, h.d_out, h.out_cap);
+            if (h.d_units) (void)hipFree(h.d_units);
+            if (h.d_res) (void)hipFree(h.d_res);
+            h.d_in = h.d_out = nullptr;
+            h.d_units = nullptr; h.d_res = nullptr;
+            h.in_cap = h.out_cap = h.unit_cap = 0;
+        }
+        lanes.clear();
+        (void)hipSetDevice(c->device);
     }
     int open()
     {
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, semz_pool_take(c, in_len + 64, (void **)&d_in, &d_in_cap));
-        HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+        budget = c->batch_budget;
+        if (!budget) {
+            size_t fr = 0, tot = 0;
+            HIPCHK(c, hipMemGetInfo(&fr, &tot));
+            for (auto &b : c->pool) fr += b.cap;                  // (what the pool holds is the library's to use)
+            budget = (uint64_t)fr / 4 * 3;
+        }
         for (semz_ctx *hc : c->helpers) {
             Helper h;
             h.c = hc;
             helpers.push_back(h);
         }
+        // an input that takes a good part of the budget by itself goes up window by window, or, if the format has
+        // no units to predict, when the first decode asks for it
+        if (in_len > budget / 4) return 0;
+        return ensure_input();
+    }
+    int ensure_input()
+    {
+        if (d_in) return 0;
+        hipError_t e = semz_pool_take(c, in_len + 64, (void **)&d_in, &d_in_cap);
+        if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); d_in = nullptr; return RC_OOM; }
+        HIPCHK(c, e);
+        HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
         return 0;
     }
     // Sizes that come out of the data (declared sizes, index records, ISIZE fields) are untrusted: a request the
@@ -159,6 +219,18 @@ struct Run {
     }
     int decode_on_primary(const semz_unit *units, size_t n, semz_result *res, uint64_t arena_base, uint64_t arena_room)
     {
+        {
+            int rc = ensure_input();
+            if (rc == RC_OOM) {                                   // (the input does not fit the device: nothing can be decoded from it here)
+                for (size_t i = 0; i < n; i++) {
+                    res[i] = semz_result{};
+                    res[i].status = SEMZ_E_NO_MEMORY;
+                    res[i].in_end_bit = 8 * units[i].in_off + units[i].in_bit_off;
+                }
+                return 0;
+            }
+            if (rc) return rc;
+        }
         if (n > unit_cap) {
             if (d_units) HIPCHK(c, hipFree(d_units));
             if (d_res) HIPCHK(c, hipFree(d_res));
@@ -225,6 +297,189 @@ struct Run {
         h.out_used += (size_t)r.out_room;
         return 0;
     }
+    // ---- the batch loop ----
+    // does a predicted batch of `total` output bytes and `scratch` bytes of decoder scratch go window by window?
+    bool want_windows(uint64_t total, uint64_t scratch) const
+    {
+        const uint64_t need = (uint64_t)in_len + total + scratch;
+        return need > budget || need < total;
+    }
+    // Decodes `units` window by window into host memory.  The results are in the frame of the batch like those of
+    // decode(): the caller adds `frame_base` to every out_off and gets the tagged offset of the bytes.  No arena of
+    // the primary device is used.  `out_need[i]`: the room unit i asks for (multi.h: window_units).
+    int decode_windowed(std::vector<semz_unit> &units, std::vector<semz_result> &res, const std::vector<uint64_t> &out_need,
+                        uint64_t frame_total, uint64_t frame_base, uint64_t unit_scratch)
+    {
+        const size_t n = units.size();
+        res.assign(n, semz_result{});
+        distrust.assign(n, 0);
+        if (!n) return 0;
+        if (lanes.empty()) {
+            while (c->lanes.size() < 2) {
+                semz_ctx *l = nullptr;
+                if (semz_open(c->device, &l)) return semz_fail(c, -2, "batch loop: no further context on device %d", c->device);
+                l->lz_no_fast = c->lz_no_fast;
+                c->lanes.push_back(l);
+            }
+            for (semz_ctx *l : c->lanes) {
+                Helper h;
+                h.c = l;
+                lanes.push_back(h);
+            }
+            for (auto &x : helpers) {                                 // (with buffers of the batch loop's own)
+                Helper h;
+                h.c = x.c;
+                lanes.push_back(h);
+            }
+        }
+        // two lanes share the primary device with the whole input, if that is resident
+        const uint64_t resident = d_in ? std::min<uint64_t>(in_len, budget / 2) : 0;
+        const uint64_t limit = std::max<uint64_t>((budget - resident) / 2, 1u << 20);
+        const std::vector<MultiRange> wins = window_units(units.data(), n, in_len, out_need.data(), limit, 1u << 16, unit_scratch);
+        if (wins.size() >= (1u << (MULTI_TAG_SHIFT - WINDOW_SHIFT))) return semz_fail(c, -4, "batch loop: %zu windows", wins.size());
+        const size_t chunk0 = chunks.size();
+        chunks.resize(chunk0 + wins.size());
+        // the caller's buffer takes the windows where the stream will have them, if the batch is the stream so far
+        const bool fixed = units[0].out_off != SEMZ_OUT_AUTO;
+        const bool in_place = fixed && sink && emitted == 0 && chunk0 == 0 && frame_total <= sink_cap;
+        std::atomic<size_t> next{0};
+        std::vector<int> rcs(lanes.size(), 0);
+        std::vector<uint8_t> oom(wins.size(), 0);
+        auto work = [&](size_t li) {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= wins.size()) return;
+                int rc = decode_window(lanes[li], units.data(), wins[k], chunk0 + k, in_place, frame_base, res.data());
+                if (rc == RC_OOM) oom[k] = 1;
+                else if (rc) {
+                    rcs[li] = rc;
+                    next.store(wins.size());
+                    return;
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (size_t li = 1; li < lanes.size() && li < wins.size(); li++) th.emplace_back(work, li);
+        work(0);
+        for (auto &t : th) t.join();
+        HIPCHK(c, hipSetDevice(c->device));
+        windows_run += wins.size();
+        for (size_t li = 0; li < lanes.size(); li++)
+            if (rcs[li]) return semz_fail(c, rcs[li], "batch loop, device %d: %s", lanes[li].c->device, lanes[li].c->err);
+        for (size_t k = 0; k < wins.size(); k++)
+            if (oom[k])                                               // the walk decodes these on demand (or reports the memory)
+                for (size_t i = 0; i < wins[k].count; i++) distrust[wins[k].first + i] = 1;
+        return 0;
+    }
+    int decode_window(Helper &h, const semz_unit *units, const MultiRange &r, size_t chunk, bool in_place, uint64_t frame_base,
+                      semz_result *res)
+    {
+        semz_ctx *hc = h.c;
+        semz_ctx *pc = hc->device == c->device ? c : hc;              // whose pool the buffers come from
+        HIPCHK(hc, hipSetDevice(hc->device));
+        const size_t span = (size_t)(r.in_hi - r.in_lo);
+        if (span + 64 > h.in_cap) {
+            pool_give_locked(pc, h.d_in, h.in_cap);
+            h.d_in = nullptr;
+            h.in_cap = 0;
+            hipError_t e = pool_take_locked(pc, span + 64, (void **)&h.d_in, &h.in_cap);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
+            HIPCHK(hc, e);
+        }
+        HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(units, r, local, clamped);
+        const size_t n = r.count;
+        if (n > h.unit_cap) {
+            if (h.d_units) HIPCHK(hc, hipFree(h.d_units));
+            if (h.d_res) HIPCHK(hc, hipFree(h.d_res));
+            h.d_units = nullptr; h.d_res = nullptr;
+            h.unit_cap = n + n / 2 + 16;
+            HIPCHK(hc, hipMalloc((void **)&h.d_units, h.unit_cap * sizeof(semz_unit)));
+            HIPCHK(hc, hipMalloc((void **)&h.d_res, h.unit_cap * sizeof(semz_result)));
+        }
+        HIPCHK(hc, hipMemcpyAsync(h.d_units, local.data(), n * sizeof(semz_unit), hipMemcpyHostToDevice, hc->stream));
+        std::vector<semz_result> lres(n);
+        uint64_t room = r.out_room;
+        for (int attempt = 0;; attempt++) {
+            if (room > (SIZE_MAX >> 2)) return RC_OOM;
+            if (room + 64 > h.out_cap) {
+                pool_give_locked(pc, h.d_out, h.out_cap);
+                h.d_out = nullptr;
+                h.out_cap = 0;
+                hipError_t e = pool_take_locked(pc, (size_t)room + 64, (void **)&h.d_out, &h.out_cap);
+                if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }
+                HIPCHK(hc, e);
+            }
+            HIPCHK(hc, hipMemsetAsync(h.d_res, 0xFF, n * sizeof(semz_result), hc->stream));
+            int rc = semz_decode_batch_device(hc, local[0].kind, h.d_in, span, h.d_units, n, h.d_out, (size_t)room, h.d_res);
+            if (rc) return rc;
+            HIPCHK(hc, hipMemcpyAsync(lres.data(), h.d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, hc->stream));
+            HIPCHK(hc, hipStreamSynchronize(hc->stream));
+            // outputs the device packs (bzip2 blocks) may need more room than the estimate: RLE1 expands
+            bool cap = false;
+            if (!r.fixed)
+                for (auto &x : lres) cap = cap || x.status == SEMZ_E_OUT_CAP;
+            if (!cap || attempt == 3) break;
+            room = sat4(room);
+        }
+        uint64_t used = 0;
+        if (r.fixed) used = r.out_room;
+        else
+            for (auto &x : lres)
+                if (x.status == SEMZ_OK && x.out_off + x.out_len > used) used = x.out_off + x.out_len;
+        HostChunk &k = chunks[chunk];
+        k.len = used;
+        if (in_place) k.p = sink + r.out_lo;
+        else if (used) {
+            if (used >= (8u << 20)) {
+                k.p = (uint8_t *)aligned_alloc(2u << 20, (used + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+                if (k.p) madvise(k.p, used, MADV_HUGEPAGE);
+            } else k.p = (uint8_t *)malloc(used);
+            if (!k.p) return semz_fail(hc, -5, "out of host memory (%llu bytes)", (unsigned long long)used);
+            k.owned = true;
+        }
+        if (used) {
+            int rc = download(hc, k.p, h.d_out, used);
+            if (rc) return rc;
+            HIPCHK(hc, hipStreamSynchronize(hc->stream));
+        }
+        globalise_results(r, WINDOW_TAG, (uint64_t)chunk << WINDOW_SHIFT, frame_base, clamped, lres.data(), res, distrust.data());
+        return 0;
+    }
+    // A predicted batch of units with fixed spans laid out in [0, total): into the arena behind out_used, or,
+    // beyond the budget, window by window.  RC_OOM: the arena could not be had.  The caller adds out_used to the
+    // results' offsets either way and moves out_used on by `total` unless `windowed` comes back set.
+    int predecode(std::vector<semz_unit> &units, std::vector<semz_result> &res, uint64_t total, bool &windowed)
+    {
+        windowed = want_windows(total, 0);
+        if (windowed) {
+            std::vector<uint64_t> need(units.size());
+            for (size_t i = 0; i < units.size(); i++) need[i] = units[i].out_cap;
+            return decode_windowed(units, res, need, total, out_used, 0);
+        }
+        int rc = reserve(total);
+        if (rc) return rc;
+        return decode(units, res, out_used, total);
+    }
+    static uint64_t sat4(uint64_t v) { return v > (~0ull >> 2) ? ~0ull : v * 4; }
+    // (the lanes of the primary device take their buffers from one pool, from several threads)
+    static std::mutex &pool_mutex()
+    {
+        static std::mutex m;
+        return m;
+    }
+    static hipError_t pool_take_locked(semz_ctx *pc, size_t bytes, void **p, size_t *cap)
+    {
+        std::lock_guard<std::mutex> g(pool_mutex());
+        return semz_pool_take(pc, bytes, p, cap);
+    }
+    static void pool_give_locked(semz_ctx *pc, void *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> g(pool_mutex());
+        semz_pool_give(pc, p, cap);
+    }
     // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP.
     // `limit` is the largest span that can be of use (a declared size, or what the format can expand to from the
     // bytes that are left); a span the device cannot give is SEMZ_E_NO_MEMORY for the stream, not a failed call.
@@ -274,7 +529,9 @@ struct Run {
             h.d_in = nullptr; h.d_units = nullptr; h.d_res = nullptr; h.unit_cap = 0; h.in_cap = 0;
         }
         if (!helpers.empty()) (void)hipSetDevice(c->device);
+        release_lanes();
         in = nullptr;                          // no host pointer is kept beyond the call
+        sink = nullptr;                        // (chunks inside the caller's buffer are only read by the call itself)
     }
     // Device to host.  A copy into pageable memory is staged by the runtime on the calling thread and runs at the
     // speed of that thread's memcpy (17 GB/s here); a large one is therefore cut into slices that go side by side,
@@ -317,13 +574,38 @@ struct Run {
     {
         if (off > emitted || len > emitted - off) return semz_fail(c, -1, "semz_stream_read: range beyond the decoded stream");
         std::vector<uint8_t> used(helpers.size(), 0);
+        // Windows of the batch loop are in host memory already, and when the call decodes into the caller's buffer
+        // most of them are where they belong.  The ones that are not (the walk did not take the prediction as it
+        // was) may lie where other spans have to go: they are set aside first.
+        struct Moved { uint8_t *dst; std::vector<uint8_t> bytes; };
+        std::vector<Moved> moved;
+        {
+            uint64_t at = 0, o = off, l = len;
+            uint8_t *d = dst;
+            for (auto &sp : spans) {
+                if (!l) break;
+                if (o < at + sp.len) {
+                    const uint64_t skip = o - at, take = std::min<uint64_t>(l, sp.len - skip);
+                    if (multi_dev(sp.off) == WINDOW_TAG) {
+                        const HostChunk &k = chunks[multi_off(sp.off) >> WINDOW_SHIFT];
+                        const uint8_t *src = k.p + (multi_off(sp.off) & ((1ull << WINDOW_SHIFT) - 1)) + skip;
+                        if (!k.owned && src != d) moved.push_back(Moved{d, std::vector<uint8_t>(src, src + take)});
+                    }
+                    d += take; o += take; l -= take;
+                }
+                at += sp.len;
+            }
+        }
         uint64_t at = 0;
         for (auto &sp : spans) {
             if (!len) break;
             if (off < at + sp.len) {
                 const uint64_t skip = off - at, take = std::min<uint64_t>(len, sp.len - skip);
                 const unsigned dev = multi_dev(sp.off);
-                if (dev == 0) {
+                if (dev == WINDOW_TAG) {
+                    const HostChunk &k = chunks[multi_off(sp.off) >> WINDOW_SHIFT];
+                    if (k.owned) memcpy(dst, k.p + (multi_off(sp.off) & ((1ull << WINDOW_SHIFT) - 1)) + skip, take);
+                } else if (dev == 0) {
                     int rc = download(c, dst, d_out + sp.off + skip, take);
                     if (rc) return rc;
                 } else {
@@ -344,6 +626,8 @@ struct Run {
             }
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &m : moved) memcpy(m.dst, m.bytes.data(), m.bytes.size());
+        c->last_moved = moved.size();
         return 0;
     }
     void emit(uint64_t off, uint64_t len)
@@ -437,18 +721,17 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                 total += u.out_cap;                               // back to back: the stream's output stays one span
                 units.push_back(u);
             }
-            int rc = units.size() > 1 ? R.reserve(total) : Run::RC_OOM;
+            std::vector<semz_result> res;
+            bool windowed = false;
+            int rc = units.size() > 1 ? R.predecode(units, res, total, windowed) : Run::RC_OOM;
             if (rc && rc != Run::RC_OOM) { free(su); return rc; }
             if (rc == 0) {
-                std::vector<semz_result> res;
-                rc = R.decode(units, res, R.out_used, total);
-                if (rc) { free(su); return rc; }
                 for (size_t i = 0; i < units.size(); i++) {
                     if (res[i].status == SEMZ_E_OUT_CAP || R.distrust[i]) continue;
                     res[i].out_off += R.out_used;
                     pre[units[i].in_off] = res[i];
                 }
-                R.out_used += total;
+                if (!windowed) R.out_used += total;
             }
         }
         free(su);
@@ -487,20 +770,28 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
                 // (look-alike headers in a large single member can hypothesise gigabytes each: speculation is only
                 // worth a bounded amount of memory, otherwise the members are decoded one after the other)
                 const double tr1 = now();
-                int rc = units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len) ? R.reserve(total) : Run::RC_OOM;
+                if (R.want_windows(total, 0)) {
+                    // (window by window into host memory: back to back without the padding, which is how the
+                    // stream has the members if the hypotheses hold)
+                    total = 0;
+                    for (auto &u : units) {
+                        u.out_off = total;
+                        total += u.out_cap;
+                    }
+                }
+                std::vector<semz_result> res;
+                bool windowed = false;
+                int rc = units.size() >= 2 && total <= std::max<uint64_t>(64ull << 20, 16 * R.in_len) ? R.predecode(units, res, total, windowed)
+                                                                                                     : Run::RC_OOM;
                 if (rc && rc != Run::RC_OOM) return rc;
-                const double tr2 = now();
                 if (rc == 0) {
-                    std::vector<semz_result> res;
-                    rc = R.decode(units, res, R.out_used, total);
-                    if (rc) return rc;
-                    if (trace) fprintf(stderr, "gzip members: candidates %.1f ms (%zu), arena %.1f ms, upload wait + decode %.1f ms\n", tr1 - tr0, cand.size(), tr2 - tr1, now() - tr2);
+                    if (trace) fprintf(stderr, "gzip members: candidates %.1f ms (%zu), arena + upload wait + decode %.1f ms, %zu windows\n", tr1 - tr0, cand.size(), now() - tr1, R.windows_run);
                     for (size_t i = 0; i < units.size(); i++) {
                         if (res[i].status == SEMZ_E_OUT_CAP || R.distrust[i]) continue;        // the hypothesis did not hold
                         res[i].out_off += R.out_used;
                         pre[units[i].in_off] = res[i];
                     }
-                    R.out_used += total;
+                    if (!windowed) R.out_used += total;
                 }
             }
         }
@@ -562,7 +853,14 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
     std::map<uint64_t, size_t> by_bit;
     std::vector<semz_result> res;
     uint64_t arena0 = R.out_used;
-    for (;;) {
+    const bool windowed = !units.empty() && R.want_windows(guess, sat_mul(units.size(), semz_bzip2_scratch_per_block()));
+    if (windowed) {
+        std::vector<uint64_t> need(units.size());
+        for (size_t i = 0; i < units.size(); i++) need[i] = (uint64_t)units[i].param0 * 100000 + 4096;
+        int rc = R.decode_windowed(units, res, need, guess, arena0, semz_bzip2_scratch_per_block());
+        if (rc) return rc;
+    }
+    while (!windowed) {
         int rc = R.reserve(guess);
         if (rc == Run::RC_OOM) { oc.status = SEMZ_E_NO_MEMORY; return 0; }
         if (rc) return rc;
@@ -574,7 +872,7 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
         guess = sat_mul(guess, 4);                                // RLE1 can expand far beyond the block size
     }
     for (size_t i = 0; i < units.size(); i++) {
-        if (R.distrust[i]) continue;                              // (decoded from a cut span on another device: see multi.h)
+        if (R.distrust[i] || res[i].status == SEMZ_E_OUT_CAP) continue;   // (decoded from a cut span: see multi.h; or a window's room ran out)
         by_bit[start_bits[i]] = i;
         const uint64_t end = arena0 + res[i].out_off + res[i].out_len;
         if (res[i].status == SEMZ_OK && multi_dev(arena0 + res[i].out_off) == 0 && end > R.out_used) R.out_used = end;
@@ -654,18 +952,17 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
             // and the sum cannot wrap; an arena the device cannot give means "no prediction" (the walk below then
             // decodes block by block and reports what the reference would, an index mismatch at the end).
             std::vector<semz_unit> units(su, su + sn);
-            int rc = R.reserve(si.total_out);
+            std::vector<semz_result> res;
+            bool windowed = false;
+            int rc = R.predecode(units, res, si.total_out, windowed);
             if (rc && rc != Run::RC_OOM) { free(su); return rc; }
             if (rc == 0) {
-                std::vector<semz_result> res;
-                rc = R.decode(units, res, R.out_used, si.total_out);
-                if (rc) { free(su); return rc; }
                 for (size_t i = 0; i < sn; i++) {
                     if (R.distrust[i]) continue;
                     res[i].out_off += R.out_used;
                     pre[units[i].in_off] = std::make_pair(units[i], res[i]);
                 }
-                R.out_used += si.total_out;
+                if (!windowed) R.out_used += si.total_out;
             }
         }
         free(su);
@@ -901,8 +1198,9 @@ extern "C" void semz_stream_release(semz_decoded *d)
     delete d;
 }
 
-extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members,
-                                  semz_decoded **decoded, semz_result *res, semz_stream_info *info)
+// `sink`: the buffer the caller wants the stream in (semz_decode_stream_into), which the batch loop fills directly
+static int stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members, uint8_t *sink, size_t sink_cap,
+                         semz_decoded **decoded, semz_result *res, semz_stream_info *info)
 {
     if (!c) return -1;
     if (!decoded || !res || (!in && in_len)) return semz_fail(c, -1, "null pointer");
@@ -916,6 +1214,8 @@ extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_
     const double t0 = now();
     semz_decoded *Rp = new semz_decoded{Run{c, in, in_len}};
     Run &R = Rp->run;
+    R.sink = sink;
+    R.sink_cap = sink_cap;
     // (the upload from pageable memory keeps this thread busy: the scan for gzip member starts runs beside it)
     std::thread scanner;
     if (fmt == SEMZ_FMT_GZIP && all_members && in_len >= (1u << 20))
@@ -950,8 +1250,9 @@ extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_
     }
     if (rc) { delete Rp; return rc; }
     const double t2 = now();
+    c->last_windows = R.windows_run;
     R.drop_working_set();
-    if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms, drop %.1f ms\n", t1 - t0, t2 - t1, now() - t2);
+    if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms, drop %.1f ms, %zu windows\n", t1 - t0, t2 - t1, now() - t2, R.windows_run);
     res->status = oc.status;
     res->detail = oc.detail;
     res->in_end_bit = 8 * oc.consumed;
@@ -960,6 +1261,12 @@ extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_
     if (info) *info = si;
     *decoded = Rp;
     return 0;
+}
+
+extern "C" int semz_stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len, int all_members,
+                                  semz_decoded **decoded, semz_result *res, semz_stream_info *info)
+{
+    return stream_decode(c, fmt, in, in_len, all_members, nullptr, 0, decoded, res, info);
 }
 
 extern "C" int semz_stream_members(const semz_decoded *d, const semz_member **members, size_t *nmembers)
@@ -987,7 +1294,7 @@ extern "C" int semz_decode_stream_into(semz_ctx *c, int fmt, const uint8_t *in, 
     if (!out_len || (!out && out_cap)) return semz_fail(c, -1, "null pointer");
     *out_len = 0;
     semz_decoded *d = nullptr;
-    int rc = semz_stream_decode(c, fmt, in, in_len, all_members, &d, res, info);
+    int rc = stream_decode(c, fmt, in, in_len, all_members, out, out_cap, &d, res, info);
     if (rc) return rc;
     Run *R = &d->run;
     *out_len = R->emitted;

@@ -187,8 +187,19 @@ int semz_decode_batch_device_noalloc(semz_ctx *ctx, uint32_t kind, const void *d
  * "lc", "lp", "pb", "decompressed-size" (< 0 = nil), "eof-mode" (0 :maybe, 1 :always, 2 :never) = the
  * keywords of the :raw-lzma format (lzma.lisp:809-825).  "lzma-honour-size" = 1 makes SEMZ_FMT_LZMA
  * honour the size its header declares (off = the reference as written).
- * "lzma-no-fast" = 1 decodes xz / LZMA2 units with the general kernel only (for measurements). */
+ * "lzma-no-fast" = 1 decodes xz / LZMA2 units with the general kernel only (for measurements).
+ * "batch-budget" = the device bytes (input, output, decoder scratch) a predicted batch of a stream call
+ * may take; a larger one is decoded window by window into host memory -- straight into the caller's
+ * buffer for semz_decode_stream_into -- with the upload of one window, the kernels of another and the
+ * download of a third side by side (the reference's bounded chunks, common.lisp:255-257, and its rule that
+ * nothing delivered is lost before an error, interface.lisp:91-133).  0 (the default) = three quarters of
+ * the memory the device has free when the call starts. */
 int semz_set_option(semz_ctx *ctx, const char *name, long value);
+/* Reads "batch-budget", "profile", "window-size" back, and "windows": the number of windows the last stream
+ * call on this context decoded (0 = its batch went in one piece), and "moved": how many pieces of such windows
+ * the last read found in the caller's buffer at another place than the stream has them (the walk did not take
+ * the prediction as it was) and moved.  No counterpart in the reference. */
+int semz_get_option(semz_ctx *ctx, const char *name, long *value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */
 int semz_profile_count(semz_ctx *ctx);

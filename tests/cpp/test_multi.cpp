@@ -86,8 +86,66 @@ static void check(size_t n, unsigned parts, bool fixed, bool fail_cut)
         }
 }
 
+// the batch loop's windows: contiguous, complete, every one within the limit unless it is a single unit, and the
+// merge with window tags (device 255, window number in the offset's high bits) names window and place
+static void check_windows(size_t n, uint64_t limit, bool fixed, uint64_t unit_scratch)
+{
+    const uint64_t in_len = 1000 * n + 77, margin = 64;
+    std::vector<semz_unit> u;
+    std::vector<uint64_t> need;
+    uint64_t out = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t cap = 100 + 7 * (i % 13) + (i % 17 == 5 ? 5000 : 0);
+        u.push_back(unit(1000 * i + (i % 3), in_len, fixed ? out : SEMZ_OUT_AUTO, fixed ? cap : 0));
+        need.push_back(cap);
+        out += cap;
+    }
+    auto wins = window_units(u.data(), n, in_len, need.data(), limit, margin, unit_scratch);
+    size_t at = 0;
+    std::vector<semz_result> res(n);
+    std::vector<uint8_t> distrust(n, 0xAA);
+    const uint64_t frame_base = 12345;
+    for (size_t w = 0; w < wins.size(); w++) {
+        const MultiRange &r = wins[w];
+        assert(r.first == at && r.count > 0);
+        at += r.count;
+        assert(r.in_lo == u[r.first].in_off && r.in_hi <= in_len);
+        if (w + 1 < wins.size()) assert(r.in_hi >= u[wins[w + 1].first].in_off);
+        uint64_t room = 0;
+        for (size_t i = 0; i < r.count; i++) room += need[r.first + i];
+        assert(r.out_room == room);                                   // (fixed spans lie back to back here)
+        const uint64_t cost = (r.in_hi - r.in_lo) + room + r.count * unit_scratch;
+        assert(cost <= limit || r.count == 1);
+        // greedy: the next unit would not have fitted
+        if (w + 1 < wins.size() && r.count >= 1) {
+            const size_t e = r.first + r.count;
+            uint64_t h = e + 1 < n ? u[e + 1].in_off : in_len;
+            h = h + margin < in_len ? h + margin : in_len;
+            assert((h - r.in_lo) + room + need[e] + (r.count + 1) * unit_scratch > limit);
+        }
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(u.data(), r, local, clamped);
+        auto lres = fake_device(local, clamped, true);
+        globalise_results(r, 255, (uint64_t)w << 40, frame_base, clamped, lres.data(), res.data(), distrust.data());
+    }
+    assert(at == n);
+    for (size_t w = 0; w < wins.size(); w++)
+        for (size_t i = wins[w].first; i < wins[w].first + wins[w].count; i++) {
+            const uint64_t off = res[i].out_off + frame_base;
+            assert(multi_dev(off) == 255 && (multi_off(off) >> 40) == w);
+            if (fixed) assert((multi_off(off) & ((1ull << 40) - 1)) == u[i].out_off - wins[w].out_lo);
+            assert(res[i].in_end_bit == 8 * (u[i].in_off + 10));
+            assert(distrust[i] == (uint8_t)(u[i].in_limit > wins[w].in_hi));
+        }
+}
+
 int main()
 {
+    for (size_t n : {1, 2, 3, 7, 64, 1000})
+        for (uint64_t limit : {1ull, 3000ull, 20000ull, 1ull << 40})
+            for (int fixed = 0; fixed < 2; fixed++)
+                for (uint64_t scratch : {0ull, 700ull}) check_windows(n, limit, fixed != 0, scratch);
     for (size_t n : {1, 2, 3, 7, 64, 1000})
         for (unsigned parts : {1u, 2u, 3u, 8u})
             for (int fixed = 0; fixed < 2; fixed++)
