@@ -142,7 +142,6 @@ struct BzShare {           // producer/consumer hand-over (LDS, workgroup-scope 
 
 struct __align__(16) BzLds {
     uint8_t inbuf[BZ_IN_RING];
-    uint32_t sel4[4096];                 // selectors, 4 bits each (the count field has 15 bits)
     BzTree tree[6];
     uint8_t lens[260];
     uint8_t symbols[256];
@@ -308,7 +307,7 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
 }
 
 __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units, uint32_t nunits,
-                                                        uint64_t out_total, bz_meta *meta, uint8_t *pre_all)
+                                                        uint64_t out_total, bz_meta *meta, uint8_t *pre_all, uint8_t *post_all)
 {
     // Two waves per block, a producer and a consumer, joined by a symbol queue in LDS.  A lone wave issues one
     // instruction every ~5 clocks whatever its kind and a bzip2 batch has fewer blocks than the chip has SIMDs,
@@ -349,6 +348,10 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
         return;
     }
     uint8_t *pre = pre_all + (size_t)u * BZ_STRIDE;
+    // The selectors (four bits each, up to 2^15 - 1 of them: 16 KiB) wait in the block's `post` array, which
+    // nothing else uses before bz_link_kernel, and come back 512 at a time into one vector register: LDS is what
+    // bounds the number of blocks a CU holds, and a batch of config 3's size has six times as many blocks as fit.
+    uint32_t *selg = reinterpret_cast<uint32_t *>(post_all + (size_t)u * BZ_STRIDE);
     const uint32_t level = un.param0 >= 1 && un.param0 <= 9 ? un.param0 : 9;
     const uint32_t block_size = level * 100000u;
     const uint64_t amis = (uint64_t)((uintptr_t)in & 15);
@@ -413,10 +416,11 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                     stack = high | (low << 4) | val;
                     packed |= val << (4 * (i & 7));
                     if ((i & 7) == 7 || i + 1 == nsel) {
-                        if (lane == 0) L.sel4[i >> 3] = packed;
+                        if (lane == 0) selg[i >> 3] = packed;
                         packed = 0;
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (written by this wave, read back below)
             }
             // read-bzip2-trees (bzip2.lisp:317-343): 5-bit start, then 0 = emit, 10 = +1, 11 = -1
             for (uint32_t t = 0; t < ntrees; t++) {
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
             const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(L.inbuf);
             uint32_t produced = 0, consumed_seen = 0;
             uint32_t g = 0, k = BZ_GROUP, t = 0, maxlen = 0;
+            uint32_t selw = 0, selblk = ~0u;                // lane j: the 8 selectors 512 selblk + 8 j ..
             P = br.bitpos();
             in_symbols = true;
             BZ_STAMP(0);
@@ -465,7 +470,11 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 }
                 if (k == (uint32_t)BZ_GROUP) {
                     if (g >= nsel) BZ_FAIL(SEMZ_E_BZ_SELECTORS_EXHAUSTED, 0);
-                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)((L.sel4[g >> 3] >> (4 * (g & 7))) & 15));
+                    if ((g >> 9) != selblk) {
+                        selblk = g >> 9;
+                        selw = __hip_atomic_load(selg + 64 * selblk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    t = ((uint32_t)__builtin_amdgcn_readlane((int)selw, (int)((g >> 3) & 63)) >> (4 * (g & 7))) & 15;
                     maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tree[t].maxlen);
                     g++;
                     k = 0;
@@ -1305,7 +1314,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     uint8_t *temp = (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t);
     if (hipMemsetAsync(ctl, 0, ctl_bytes, c->stream) != hipSuccess) return semz_fail(c, -2, "hipMemsetAsync failed");
     semz_span_begin(c, "bz_decode_kernel");
-    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre);
+    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)post);
     semz_span_end(c);
     semz_span_begin(c, "bz_sort_kernel");
     bz_sort_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt);
