@@ -29,7 +29,13 @@
 namespace {
 
 constexpr uint32_t BZ_STRIDE = 900032;         // per-block scratch stride (bytes / entries)
-constexpr int BZ_ROOT_BITS = 11;              // root table index width; longer codes are resolved from limit[]
+// Root table index width of the Huffman trees; longer codes are resolved from limit[].  LDS bounds the number of
+// blocks a CU holds (two waves each): 33 KB per block with 11-bit roots (four per CU, 1024 on the chip), 12.5 KB
+// with 8-bit roots (twelve per CU).  A batch that fits the chip with the wide tables takes them (fewer long
+// codes: 28.4 against 30.4 ms for 600 blocks); a larger one is better off with more blocks in flight
+// (4800 blocks: 135 ms with 11 bits, 96 with 10, 86 with 9, 79 with 8).
+constexpr int BZ_ROOT_WIDE = 11, BZ_ROOT_NARROW = 8;
+constexpr uint32_t BZ_WIDE_BLOCKS = 1024;      // batches up to this many blocks use the wide tables
 constexpr int BZ_QCAP = 1024;                  // LDS symbol queue between the Huffman wave and the MTF wave
 constexpr int BZ_IN_HALF = 1024;               // input is staged in aligned 1 KiB pieces ...
 constexpr int BZ_IN_RING = 2 * BZ_IN_HALF;     // ... into a two-piece LDS ring
@@ -121,7 +127,7 @@ __constant__ uint16_t BZ_RAND[512] = {
  780,773,635,389,707,100,626,958,165,504,920,176,193,713,857,265,203,50,668,108,
  645,990,626,197,510,357,358,850,858,364,936,638 };
 
-struct BzTree {
+template <int BZ_ROOT_BITS> struct BzTree {
     uint16_t root[1 << BZ_ROOT_BITS];   // (symbol << 5) | length, 0 = code longer than the root
     uint16_t sorted[260];
     uint32_t limit[21];                  // (first+count) << (20-len)
@@ -140,9 +146,9 @@ struct BzShare {           // producer/consumer hand-over (LDS, workgroup-scope 
     uint32_t detail, orig, randomized, want_crc, end_lo, end_hi;
 };
 
-struct __align__(16) BzLds {
+template <int BZ_ROOT_BITS> struct __align__(16) BzLds {
     uint8_t inbuf[BZ_IN_RING];
-    BzTree tree[6];
+    BzTree<BZ_ROOT_BITS> tree[6];
     uint8_t lens[260];
     uint8_t symbols[256];
     uint16_t count[32];
@@ -256,7 +262,7 @@ struct MsbReader {
 };
 
 // One canonical tree from lens[0..n) (lengths->ht :be, huffman.lisp:142-225).
-__device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
+template <int BZ_ROOT_BITS> __device__ int bz_build_tree(BzLds<BZ_ROOT_BITS> &L, BzTree<BZ_ROOT_BITS> &T, int n)
 {
     const int lane = threadIdx.x & 63;
     uint32_t c = 0;
@@ -306,6 +312,7 @@ __device__ int bz_build_tree(BzLds &L, BzTree &T, int n)
     return SEMZ_OK;
 }
 
+template <int BZ_ROOT_BITS>
 __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint64_t in_len, const semz_unit *units, uint32_t nunits,
                                                         uint64_t out_total, bz_meta *meta, uint8_t *pre_all, uint8_t *post_all)
 {
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
     // reported once the consumer has drained the queue.  Both waves always reach their end: the producer sets
     // `done` on every path and leaves its wait loop when the consumer sets `abort`; the consumer only waits for
     // symbols or `done`.
-    __shared__ BzLds L;
+    __shared__ BzLds<BZ_ROOT_BITS> L;
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
     const int lane = threadIdx.x & 63;
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                     g++;
                     k = 0;
                 }
-                const BzTree &T = L.tree[t];
+                const BzTree<BZ_ROOT_BITS> &T = L.tree[t];
                 while ((P >> 3) + 16 > br.s_hi) { br.stage(); BZ_COUNT(3); }
                 BZ_COUNT(0);
                 const uint64_t bp = P + (uint32_t)lane;
@@ -488,17 +495,12 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 const uint32_t lo = __builtin_bswap32(ring32[(d + 1) & (BZ_IN_RING / 4 - 1)]);
                 const uint32_t top = (uint32_t)(((((uint64_t)hi << 32) | lo) << ((uint32_t)bp & 31)) >> 32);
                 uint32_t ev = T.root[top >> (32 - BZ_ROOT_BITS)];
-                if (__builtin_amdgcn_ballot_w64((ev & 31) == 0)) {
-                    // codes longer than the root index: every such lane searches the limits (rare)
-                    BZ_COUNT(2);
-                    const uint32_t v20 = top >> 12;
-                    for (int l = BZ_ROOT_BITS + 1; l <= 20; l++) {
-                        const uint32_t lim = T.limit[l], first = T.first[l], offs = T.offs[l];
-                        if ((ev & 31) == 0 && v20 < lim) ev = ((uint32_t)T.sorted[offs + (v20 >> (20 - l)) - first] << 5) | (uint32_t)l;
-                    }
-                }
+                // A code longer than the root index has a zero entry.  Such a lane ends the chain (length 64), and
+                // only when the chain gets there -- the lane is a real symbol start, not one of the 60 positions
+                // looked up for nothing -- is its code searched for, below.
+                const uint64_t longm = __builtin_amdgcn_ballot_w64((ev & 31) == 0);
                 // the chain of symbol starts inside this window
-                const uint32_t lenv = ev & 31;
+                const uint32_t lenv = (ev & 31) ? (ev & 31) : 64u;
                 uint64_t mask = 0;
                 uint32_t off = 0;
                 bool short_input = false;
@@ -529,6 +531,22 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                         off += len;
                     } while (off < 64);
                 }
+                if (longm & mask) {
+                    // the chain's last symbol has a long code: lane i tries length BZ_ROOT_BITS + 1 + i, the
+                    // shortest length whose limit lies above the code wins (complete trees: one does)
+                    BZ_COUNT(2);
+                    const uint32_t j = (uint32_t)__builtin_ctzll(longm & mask);
+                    const uint32_t v20 = (uint32_t)__builtin_amdgcn_readlane((int)top, (int)j) >> 12;
+                    const uint32_t l = (uint32_t)lane < 20u - BZ_ROOT_BITS ? (uint32_t)BZ_ROOT_BITS + 1 + (uint32_t)lane : 20u;
+                    const uint32_t lim = T.limit[l], first = T.first[l], offs = T.offs[l];
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(v20 < lim);
+                    const uint32_t w = hit ? (uint32_t)__builtin_ctzll(hit) : 0u;
+                    const uint32_t idx = offs + (v20 >> (20 - l)) - first;       // (only the winning lane's is meaningful)
+                    const uint32_t cand = ((uint32_t)T.sorted[idx < 260u ? idx : 0u] << 5) | l;
+                    const uint32_t found = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)w);
+                    if ((uint32_t)lane == j) ev = found;
+                    off = j + (found & 31);
+                }
                 // group boundary: symbols past it were looked up in the wrong tree
                 uint32_t cnt = (uint32_t)__builtin_popcountll(mask);
                 if (cnt > (uint32_t)BZ_GROUP - k) {
@@ -547,7 +565,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 if (eobm) {
                     const uint32_t e = (uint32_t)__builtin_ctzll(eobm);
                     qmask = mask & ((1ull << e) - 1);
-                    off = e + (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)e);
+                    off = e + ((uint32_t)__builtin_amdgcn_readlane((int)ev, (int)e) & 31);
                     finished = true;
                     short_input = false;
                 }
@@ -1314,7 +1332,10 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     uint8_t *temp = (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t);
     if (hipMemsetAsync(ctl, 0, ctl_bytes, c->stream) != hipSuccess) return semz_fail(c, -2, "hipMemsetAsync failed");
     semz_span_begin(c, "bz_decode_kernel");
-    bz_decode_kernel<<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)post);
+    if (c->bz_tables == 2 || (c->bz_tables == 0 && nunits <= BZ_WIDE_BLOCKS))
+        bz_decode_kernel<BZ_ROOT_WIDE><<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)post);
+    else
+        bz_decode_kernel<BZ_ROOT_NARROW><<<nunits, 128, 0, c->stream>>>(d_in, in_len, d_units, nunits, out_cap, (bz_meta *)meta, (uint8_t *)pre, (uint8_t *)post);
     semz_span_end(c);
     semz_span_begin(c, "bz_sort_kernel");
     bz_sort_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint8_t *)pre, (uint32_t *)tt);

@@ -158,6 +158,11 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
     }
     if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
     if (!strcmp(name, "lzma-no-fast")) { c->lz_no_fast = value != 0; return 0; }
+    if (!strcmp(name, "bzip2-tables")) {
+        if (value < 0 || value > 2) return semz_fail(c, -1, "bzip2-tables must be 0 (by batch size), 1 (narrow) or 2 (wide)");
+        c->bz_tables = (int)value;
+        return 0;
+    }
     if (!strcmp(name, "batch-budget")) {
         if (value < 0) return semz_fail(c, -1, "batch-budget must be a number of bytes (0 = automatic)");
         c->batch_budget = (uint64_t)value;

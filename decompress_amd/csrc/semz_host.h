@@ -31,6 +31,7 @@ struct semz_ctx {
     int lz_lc = -1, lz_lp = -1, lz_pb = -1, lz_eof_mode = 0;
     long long lz_size = -1;
     bool lz_honour_size = false;
+    int bz_tables = 0;                  // option "bzip2-tables": 0 = by batch size, 1 = narrow root tables, 2 = wide (tests, measurements)
     bool lz_no_fast = false;            // option "lzma-no-fast": general kernel only (A/B measurements, tests of the general kernel)
     // semz_open_multi: contexts on the other devices; the stream calls spread a predicted batch over all of them
     std::vector<semz_ctx *> helpers;

@@ -124,3 +124,26 @@ def test_out_cap_and_explicit_offsets(engine):
     units = block_units(data, 1)
     _, res = engine.decode_batch(data, units, 150000)
     assert res[0].status == 0 and res[-1].status == 200
+
+
+def test_narrow_root_tables(engine):
+    """Batches of more than 1024 blocks run bz_decode_kernel with 8-bit root tables (more blocks per CU); the option
+    forces that variant for the same checks, codes of up to 20 bits included, and one real batch goes the automatic way."""
+    engine.set_option("bzip2-tables", 1)
+    try:
+        for level in (1, 9):
+            for i, n in enumerate([1, 300, 5000, 250000]):
+                for gen in (corpus.text, corpus.random_bytes, corpus.repetitive, corpus.mixed):
+                    d = gen(n, seed=100 * i + level)
+                    check_stream(engine, bz2.compress(d, level), level, d)
+        # a steep distribution: a few frequent bytes and many rare ones give code lengths up to the limit
+        rnd = random.Random(5)
+        steep = bytes(rnd.choices(range(256), weights=[2.0 ** -(k / 9.0) for k in range(256)], k=400000))
+        check_stream(engine, bz2.compress(steep, 9), 9, steep)
+        test_corrupt_blocks(engine)
+        test_truncated_block(engine)
+    finally:
+        engine.set_option("bzip2-tables", 0)
+    parts = [corpus.mixed(1500 + 37 * (i % 41), seed=i) for i in range(1100)]
+    data = b"".join(bz2.compress(p, 1) for p in parts)
+    check_stream(engine, data, 1, b"".join(parts), cap=1 << 22)
