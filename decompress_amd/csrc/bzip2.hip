@@ -57,7 +57,7 @@ constexpr int BZ_XCDS = 8;
 constexpr int WALK_WGS = 64;                   // workgroups per XCD: 8192 lanes, one wave on every SIMD
 constexpr int WALK_THREADS = 128;
 constexpr int WALK_STEPS = 4;                  // steps between two refills of a wave's idle lanes
-constexpr int WALK_GRAB = 256;                 // chain starts a wave takes per visit to a block's counter
+constexpr int WALK_GRAB = 32;                 // chain starts a wave takes per visit to a block's counter
 
 struct bz_row {            // one row of the walk: how many bytes it holds and which row follows
     uint32_t len, next;
@@ -927,6 +927,13 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
     // wherever the workgroups were placed.
     const uint32_t home = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15) % BZ_XCDS;
     const uint32_t lane = threadIdx.x & 63;
+    // A chain's bytes collect in a row of LDS (256 bytes per lane; word w of thread t's row sits at (w + t) mod 64,
+    // so neither the lanes' own stores nor the wave's read of one row collide) and go out in one piece when the
+    // chain ends: with every lane storing a dword per four steps into a row of its own in HBM, the lines of the
+    // 8192 rows in progress (2 MB) lived in the L2 beside the vector and two thirds of the vector's reads missed.
+    __shared__ uint32_t rowbuf[WALK_THREADS * 64];
+    const uint32_t tid = threadIdx.x, wbase = threadIdx.x & ~63u;
+    uint32_t *myrow = rowbuf + tid * 64;
     uint32_t *starts = ctl;                        // per block: chain starts handed out
     uint32_t *extra = ctl + nunits;                // per block: ids handed out beyond the markers
     // the block in hand (wave-uniform)
@@ -935,13 +942,41 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
     uint32_t next = 0, end = 0;                    // this wave's share of the block's starts
     bool exhausted = false, loaded = false;
     // the chain in hand (per lane)
-    bool active = false;
-    uint32_t k = 0, len = 0, id = 0, acc = 0, smask = 0, sshift = 0, orig = 0, cap = 0, nmark = 0, blk = 0;
+    bool active = false, pend = false, cont = false;   // walking; row complete and not yet out; the chain goes on behind it
+    uint32_t k = 0, len = 0, id = 0, acc = 0, smask = 0, sshift = 0, orig = 0, cap = 0, nmark = 0, blk = 0, nxt = 0;
     const uint32_t *tt = tt_all;
-    uint32_t *row = nullptr;
     bz_row *rows = nullptr;
-    uint8_t *temp = nullptr;
     for (;;) {
+        // complete rows out, the whole wave per row: one or two full lines at a time
+        uint64_t pm = __ballot(pend);
+        if (pm) {
+            lds_sync();
+            do {
+                const uint32_t j = (uint32_t)__builtin_ctzll(pm);
+                pm &= pm - 1;
+                const uint32_t idj = (uint32_t)__builtin_amdgcn_readlane((int)id, (int)j), lenj = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)j);
+                const uint32_t blkj = (uint32_t)__builtin_amdgcn_readlane((int)blk, (int)j), capj = (uint32_t)__builtin_amdgcn_readlane((int)cap, (int)j);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(temp_all + (size_t)blkj * BZ_TEMP_STRIDE + (size_t)idj * capj);
+                const uint32_t w = rowbuf[(wbase + j) * 64 + ((lane + wbase + j) & 63)];
+                if (4 * lane < lenj) __builtin_nontemporal_store(w, dst + lane);
+            } while (pm);
+            lds_sync();
+            if (pend) {
+                pend = false;
+                if (!cont) put_row(&rows[id], len, nxt);
+                else {
+                    cont = false;
+                    const uint32_t nid = nmark + atomicAdd(&extra[blk], 1u);
+                    if (nid < (uint32_t)BZ_IDS) {
+                        put_row(&rows[id], cap, nid);
+                        id = nid;
+                        len = 0;
+                        acc = 0;
+                        active = true;
+                    } else put_row(&rows[id], cap, 0xFFFFFFFFu);   // cannot happen (BZ_IDS covers n / S + 2 + n / (4 S) + 2); ends the list
+                }
+            }
+        }
         const uint64_t idle = __ballot(!active);
         if (idle) {
             while (next >= end && !exhausted) {
@@ -988,9 +1023,7 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
                     len = 0;
                     acc = 0;
                     tt = tt_all + (size_t)cur * BZ_STRIDE;
-                    temp = temp_all + (size_t)cur * BZ_TEMP_STRIDE;
                     rows = rows_all + (size_t)cur * BZ_IDS;
-                    row = reinterpret_cast<uint32_t *>(temp + (size_t)id * cap);
                 }
             }
             const uint32_t want = (uint32_t)__popcll(idle);
@@ -1003,24 +1036,16 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
             if (active) {
                 const uint32_t v = tt[k];
                 acc |= (v & 0xFF) << (8 * (len & 3));
-                if ((len & 3) == 3) { __builtin_nontemporal_store(acc, &row[len >> 2]); acc = 0; }
+                if ((len & 3) == 3) { myrow[((len >> 2) + tid) & 63] = acc; acc = 0; }
                 k = v >> 8;
                 len++;
-                if (k == orig || (k & smask) == 0) {
-                    if (len & 3) __builtin_nontemporal_store(acc, &row[len >> 2]);
-                    put_row(&rows[id], len, k == orig ? 0u : (k >> sshift) + 1);
+                const bool fin = k == orig || (k & smask) == 0;
+                if (fin || len == cap) {
+                    if (len & 3) myrow[((len >> 2) + tid) & 63] = acc;
+                    nxt = k == orig ? 0u : (k >> sshift) + 1;
+                    cont = !fin;
+                    pend = true;
                     active = false;
-                } else if (len == cap) {
-                    const uint32_t nid = nmark + atomicAdd(&extra[blk], 1u);
-                    if (nid < (uint32_t)BZ_IDS) {
-                        put_row(&rows[id], cap, nid);
-                        id = nid;
-                        len = 0;
-                        row = reinterpret_cast<uint32_t *>(temp + (size_t)id * cap);
-                    } else {                       // cannot happen (BZ_IDS covers n / S + 2 + n / (4 S) + 2); ends the list
-                        put_row(&rows[id], cap, 0xFFFFFFFFu);
-                        active = false;
-                    }
                 }
             }
         }

@@ -14,7 +14,7 @@ o = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(o + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 for k in sorted(acc):
