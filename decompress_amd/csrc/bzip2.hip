@@ -1221,13 +1221,31 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
     }
 }
 
-// Exclusive scan of the block sizes for SEMZ_OUT_AUTO units, capacity checks, results and tails.
-__global__ void bz_offsets_kernel(const semz_unit *units, uint32_t nunits, bz_meta *meta, uint64_t out_cap,
-                                  semz_result *results, semz_tail *tails)
+// Exclusive scan of the block sizes for SEMZ_OUT_AUTO units, capacity checks, results and tails.  One workgroup:
+// a thread sums the sizes of its stretch of the blocks, the stretches' sums are scanned through LDS, and the thread
+// goes over its stretch again with the offset it starts at (a serial loop took 3.7 ms for 4800 blocks).
+constexpr int OFFS_THREADS = 1024;
+__global__ __launch_bounds__(OFFS_THREADS) void bz_offsets_kernel(const semz_unit *units, uint32_t nunits, bz_meta *meta, uint64_t out_cap,
+                                                                  semz_result *results, semz_tail *tails)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint64_t auto_off = 0;
-    for (uint32_t u = 0; u < nunits; u++) {
+    __shared__ uint64_t sums[OFFS_THREADS];
+    if (blockIdx.x != 0) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nunits + OFFS_THREADS - 1) / OFFS_THREADS;
+    const uint32_t lo = tid * per < nunits ? tid * per : nunits, hi = lo + per < nunits ? lo + per : nunits;
+    uint64_t mine = 0;
+    for (uint32_t u = lo; u < hi; u++)
+        if (meta[u].status == SEMZ_OK && units[u].out_off == SEMZ_OUT_AUTO) mine += meta[u].out_len;
+    sums[tid] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < OFFS_THREADS; d <<= 1) {          // inclusive scan
+        const uint64_t add = tid >= d ? sums[tid - d] : 0;
+        __syncthreads();
+        sums[tid] += add;
+        __syncthreads();
+    }
+    uint64_t auto_off = sums[tid] - mine;
+    for (uint32_t u = lo; u < hi; u++) {
         bz_meta m = meta[u];
         semz_result r{};
         semz_tail t{};
@@ -1372,7 +1390,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     bz_link_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (bz_meta *)meta, (uint8_t *)post, (bz_seg *)segs, temp, rows, ctl);
     semz_span_end(c);
     semz_span_begin(c, "bz_offsets_kernel");
-    bz_offsets_kernel<<<1, 64, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);
+    bz_offsets_kernel<<<1, OFFS_THREADS, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);
     semz_span_end(c);
     semz_span_begin(c, "bz_rle1_kernel");
     bz_rle1_kernel<<<nunits, 1024, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint8_t *)post,
