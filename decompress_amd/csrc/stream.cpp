@@ -455,6 +455,9 @@ struct Run {
     {
         windowed = want_windows(total, 0);
         if (windowed) {
+            // (the sizes are claims of the data: host memory of the library's own is only spent on a prediction that
+            // is plausible for the input; beyond that the walk decodes unit by unit)
+            if (total > sink_cap && total > std::max<uint64_t>(64ull << 20, sat_mul64(64, in_len))) return RC_OOM;
             std::vector<uint64_t> need(units.size());
             for (size_t i = 0; i < units.size(); i++) need[i] = units[i].out_cap;
             return decode_windowed(units, res, need, total, out_used, 0);
@@ -463,6 +466,7 @@ struct Run {
         if (rc) return rc;
         return decode(units, res, out_used, total);
     }
+    static uint64_t sat_mul64(uint64_t a, uint64_t b) { uint64_t r; return __builtin_mul_overflow(a, b, &r) ? ~0ull : r; }
     static uint64_t sat4(uint64_t v) { return v > (~0ull >> 2) ? ~0ull : v * 4; }
     // (the lanes of the primary device take their buffers from one pool, from several threads)
     static std::mutex &pool_mutex()

@@ -194,3 +194,17 @@ def test_an_input_larger_than_the_budget_is_never_resident(engines):
         assert eng.get_option("windows") >= 8
     finally:
         eng.close()
+
+
+def test_sizes_that_lie_under_a_tight_budget():
+    """The forged xz indexes and BGZF ISIZE fields of test_gpu_untrusted_sizes, with a budget that sends every
+    prediction through the batch loop: still rc 0, the oracle's status and detail, the bytes before the error."""
+    import test_gpu_untrusted_sizes as lies
+    eng = _lib.Engine(0)
+    eng.set_option("batch-budget", 1 << 18)
+    try:
+        lies.test_xz_index_that_lies(eng)
+        lies.test_bgzf_isize_that_lies(eng)
+        lies.test_block_header_sizes_that_lie(eng)
+    finally:
+        eng.close()
