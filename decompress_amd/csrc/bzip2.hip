@@ -57,6 +57,7 @@ constexpr int BZ_XCDS = 8;
 constexpr int WALK_WGS = 64;                   // workgroups per XCD: 8192 lanes, one wave on every SIMD
 constexpr int WALK_THREADS = 128;
 constexpr int WALK_STEPS = 4;                  // steps between two refills of a wave's idle lanes
+constexpr int WALK_KEEP = 24;                   // a wave goes on to its XCD's next block when this few of its lanes still walk the old one
 constexpr int WALK_GRAB = 32;                 // chain starts a wave takes per visit to a block's counter
 
 struct bz_row {            // one row of the walk: how many bytes it holds and which row follows
@@ -938,6 +939,7 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
     uint32_t *extra = ctl + nunits;                // per block: ids handed out beyond the markers
     // the block in hand (wave-uniform)
     uint32_t cur = home, lists = 0;                // block index; lists (XCDs) finished so far
+    bool gated = false;                            // the block in hand has no starts left: see below
     uint32_t c_nmark = 0, c_S = 1, c_orig = 0;
     uint32_t next = 0, end = 0;                    // this wave's share of the block's starts
     bool exhausted = false, loaded = false;
@@ -980,6 +982,20 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
         const uint64_t idle = __ballot(!active);
         if (idle) {
             while (next >= end && !exhausted) {
+                // Two vectors do not fit one L2: with the lanes that run out of starts going straight on to the
+                // next block, both blocks' reads missed for the length of the old block's last chains (seven times
+                // the lines a block has were fetched: TCC_EA0_RDREQ, one block per XCD against 75).  So a wave
+                // waits at the door of the next block until few of its own lanes still walk; the waves of an XCD
+                // are alike, so the old block is then nearly done everywhere (a count of finished chains in memory
+                // says it exactly and costs three times what it saves: atomics on one address).  With 8192 chains
+                // of 64 steps in flight the end of a block is more than half of it, so waiting costs what the
+                // misses cost: fabric reads / walk time on the 600-block bench are 238 M / 7.0 ms without the door,
+                // 193 M / 7.05 with 32 lanes, 166 M / 7.3 with 24, 130 M / 7.7 with 16, 89 M / 8.4 with 8 (and
+                // 46 M / 8.2 with markers every 32 positions, where bz_link_kernel pays 0.7 ms for the rows).
+                if (gated) {
+                    if (__popcll(__ballot(active)) > WALK_KEEP) break;
+                    gated = false;
+                }
                 if (cur >= nunits) {               // this list is done: on to the next XCD's
                     if (++lists == (uint32_t)BZ_XCDS) { exhausted = true; break; }
                     cur = (home + lists) % BZ_XCDS;
@@ -999,6 +1015,7 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 }
                 if (base >= c_nmark) {
+                    gated = c_nmark != 0;
                     cur += BZ_XCDS;
                     loaded = false;
                 } else {

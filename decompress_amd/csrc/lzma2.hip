@@ -860,21 +860,27 @@ __global__ __launch_bounds__(256) void bcj_simple_kernel(const semz_unit *units,
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide)
 {
-    semz_span_begin(c, "lzma2_kernel");
     if (wide) {
         void *w = nullptr;
         int rc = semz_scratch(c, SEMZ_SLOT_LZ_WIDE, (size_t)nunits * WIDE_LIT_PROBS * sizeof(uint16_t), &w);
         if (rc) return rc;
+        semz_span_begin(c, "lzma2_kernel");
         lzma2_kernel<true, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, (uint16_t *)w, 0);
+        semz_span_end(c);
     } else {
         // the accept-only fast kernel first; what it hands back (anything the reference would reject, unusual
         // properties, raw LZMA1) goes to the general kernel: eight units per CU, and the few units that need the
         // full literal table are redone by the third launch
-        if (!c->lz_no_fast) semz_launch_lzma2_fast(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, c->stream);
+        if (!c->lz_no_fast) {
+            semz_span_begin(c, "lzma2_fast_kernel");
+            semz_launch_lzma2_fast(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, c->stream);
+            semz_span_end(c);
+        }
+        semz_span_begin(c, "lzma2_kernel");
         lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, c->lz_no_fast ? 0 : 1);
         lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 1);
+        semz_span_end(c);
     }
-    semz_span_end(c);
     // filter chain stages (at most three non-last filters, xz.lisp:262); a kernel returns at once for
     // units whose chain has another filter, or none, at that stage
     semz_span_begin(c, "xz_filter_kernels");
