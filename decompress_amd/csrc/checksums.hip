@@ -144,6 +144,18 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
         uint32_t c = (g.beg == 0 && lane == 0) ? 0xFFFFFFFFu : 0u;
         uint64_t i = g.beg;
         for (; i < g.end && ((uintptr_t)(p + i) & 15); i++) c = t32[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
+        // (64 bytes per lane and trip: the lanes of a wave read 64 different lines, and a line should not have to
+        // wait in the cache for eight trips until its lane is through with it)
+        for (; i + 64 <= g.end; i += 64) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p + i);
+            const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                c ^= w[k];
+                c = t32[3][c & 0xFF] ^ t32[2][(c >> 8) & 0xFF] ^ t32[1][(c >> 16) & 0xFF] ^ t32[0][c >> 24];
+            }
+        }
         for (; i + 16 <= g.end; i += 16) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + i);
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -161,6 +173,16 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
         uint32_t c = (g.beg == 0 && lane == 0) ? 0xFFFFFFFFu : 0u;
         uint64_t i = g.beg;
         for (; i < g.end && ((uintptr_t)(p + i) & 15); i++) c = (c << 8) ^ t32[0][(c >> 24) ^ p[i]];
+        for (; i + 64 <= g.end; i += 64) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p + i);
+            const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                c ^= __builtin_bswap32(w[k]);
+                c = t32[3][c >> 24] ^ t32[2][(c >> 16) & 0xFF] ^ t32[1][(c >> 8) & 0xFF] ^ t32[0][c & 0xFF];
+            }
+        }
         for (; i + 16 <= g.end; i += 16) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + i);
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -178,6 +200,17 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
         uint64_t c = (g.beg == 0 && lane == 0) ? ~0ull : 0ull;
         uint64_t i = g.beg;
         for (; i < g.end && ((uintptr_t)(p + i) & 15); i++) c = t64[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
+        for (; i + 64 <= g.end; i += 64) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(p + i);
+            const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                c ^= w[k];
+                c = t64[3][c & 0xFF] ^ t64[2][(c >> 8) & 0xFF] ^ t64[1][(c >> 16) & 0xFF] ^
+                    t64[0][(c >> 24) & 0xFF] ^ (c >> 32);
+            }
+        }
         for (; i + 16 <= g.end; i += 16) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + i);
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -200,6 +233,18 @@ __global__ __launch_bounds__(64 * CK_WAVES) void checksum_kernel(const uint8_t *
         while (i < g.end) {
             uint64_t stop = g.end - i > 5552 ? i + 5552 : g.end;   // deferred modulo, adler32.lisp:63-70
             for (; i < stop && ((uintptr_t)(p + i) & 15); i++) { s1 += p[i]; s2 += s1; }
+            for (; i + 64 <= stop; i += 64) {
+                const uint4 *q = reinterpret_cast<const uint4 *>(p + i);
+                const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    s1 += w[k] & 0xFF; s2 += s1;
+                    s1 += (w[k] >> 8) & 0xFF; s2 += s1;
+                    s1 += (w[k] >> 16) & 0xFF; s2 += s1;
+                    s1 += w[k] >> 24; s2 += s1;
+                }
+            }
             for (; i + 16 <= stop; i += 16) {
                 uint4 v = *reinterpret_cast<const uint4 *>(p + i);
                 uint32_t w[4] = {v.x, v.y, v.z, v.w};
