@@ -1072,10 +1072,12 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
 // The rows in walk order, to their places in `post`.  There are tens of thousands of rows per block, so the list
 // is ranked in two levels: every id that is a multiple of BZ_SUPER heads a run of rows (id 0, origPtr's row, is
 // one of them); a thread follows each run to the next head and sums its bytes, one thread puts the runs in
-// order, then each run is followed again and its rows are copied.
+// order, and then the rows are copied side by side, a wave per row: on its way along a run the thread has noted for
+// every row which run it belongs to and where in the run it starts (`info`, two words per row), so the copy has no list
+// to follow (a thread copying the rows of its runs one dword after the other took 3 of the kernel's 4 ms).
 __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, bz_meta *meta, uint8_t *post_all,
                                                                bz_seg *seg_all, const uint8_t *temp_all, const bz_row *rows_all,
-                                                               const uint32_t *ctl)
+                                                               const uint32_t *ctl, uint2 *info_all)
 {
     constexpr uint32_t LINK_WORDS = 3 * (BZ_IDS / BZ_SUPER + 1) + 16 > 10 * BZ_SEGS ? 3 * (BZ_IDS / BZ_SUPER + 1) + 16 : 10 * BZ_SEGS;
     __shared__ __align__(16) uint32_t smem[LINK_WORDS];
@@ -1098,10 +1100,19 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
     uint32_t nids = n ? (n + S - 1) / S + 1 + ctl[nunits + u] : 0;
     if (nids > (uint32_t)BZ_IDS) nids = BZ_IDS;
     const uint32_t nrun = (nids + BZ_SUPER - 1) / BZ_SUPER;
+    uint2 *info = info_all + (size_t)u * BZ_IDS;
+    for (uint32_t i = tid; i < nids; i += BWT_THREADS) info[i] = make_uint2(0xFFFFFFFFu, 0);   // (rows no run reaches are on no cycle with a head)
+    __threadfence_block();
+    __syncthreads();
+    // When origPtr is a marker position two chains start there: id 0 and the marker's own.  Nothing links to the
+    // second one (a chain that meets origPtr is followed by id 0), but it links into the list like its twin, so a
+    // run that begins with it would claim the rows behind it a second time: it is left out.
+    const uint32_t twin = (m.orig & (S - 1)) == 0 ? m.orig / S + 1 : 0xFFFFFFFFu;
     for (uint32_t r = tid; r < nrun; r += BWT_THREADS) {
         uint32_t id = r * BZ_SUPER, sum = 0, nx = 0xFFFFFFFFu;
-        for (uint32_t guard = 0; guard < nids; guard++) {          // (a run ends at the next head; the guard is belt and braces)
+        for (uint32_t guard = 0; guard < nids && r * BZ_SUPER != twin; guard++) {   // (a run ends at the next head; the guard is belt and braces)
             const bz_row w = rows[id];
+            info[id] = make_uint2(r, sum);                         // (a run is sixteen rows on average, not at most)
             sum += w.len;
             nx = w.next;
             if (nx >= nids) { nx = 0xFFFFFFFFu; break; }
@@ -1113,6 +1124,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
         run_next[r] = nx;
         run_off[r] = 0xFFFFFFFFu;
     }
+    __threadfence_block();                         // (`info` is in global memory: __syncthreads() by itself only orders LDS)
     __syncthreads();
     if (tid == 0) {
         uint32_t t = 0, off = 0;
@@ -1126,31 +1138,40 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
     __syncthreads();
     const uint32_t cyc = misc[0];
     const uint32_t wlim = cyc < n ? cyc : n;
-    // Each run is followed again and its rows are copied: whole dwords to whatever address they belong at (the
-    // hardware takes unaligned dword stores), single bytes at a row's end.
-    for (uint32_t r = tid; r < nrun; r += BWT_THREADS) {
-        uint32_t so = run_off[r];
-        if (so == 0xFFFFFFFFu) continue;
-        uint32_t id = r * BZ_SUPER;
-        for (uint32_t guard = 0; guard < nids && so < wlim; guard++) {
-            const bz_row w = rows[id];
-            uint32_t ln = w.len < CAP ? w.len : CAP;
-            if (so + ln > wlim) ln = wlim - so;
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(temp + (size_t)id * CAP);
-            uint8_t *dst = post + so;
-            uint32_t j = 0;
-            for (; j + 4 <= ln; j += 4) {
-                const uint32_t x = src[j >> 2];
-                __builtin_memcpy(dst + j, &x, 4);
+    // The rows, 64 per wave and trip: every lane looks up where its row goes, then the wave copies the rows one
+    // after the other, a dword per lane to whatever address it belongs at (the hardware takes unaligned dword
+    // stores), single bytes at a row's end.
+    {
+        const uint32_t lane = tid & 63;
+        for (uint32_t base = tid & ~63u; base < nids; base += BWT_THREADS) {
+            const uint32_t id = base + lane;
+            uint32_t ln = 0, so = 0;
+            if (id < nids) {
+                const uint2 inf = info[id];
+                const uint32_t ro = inf.x != 0xFFFFFFFFu ? run_off[inf.x] : 0xFFFFFFFFu;
+                if (ro != 0xFFFFFFFFu && inf.y < wlim && ro < wlim - inf.y) {
+                    so = ro + inf.y;
+                    const uint32_t l = rows[id].len;
+                    ln = l < CAP ? l : CAP;
+                    if (so >= wlim) ln = 0;
+                    else if (so + ln > wlim) ln = wlim - so;
+                }
             }
-            if (j < ln) {
-                uint32_t x = src[j >> 2];
-                for (; j < ln; j++, x >>= 8) dst[j] = (uint8_t)x;
+            uint64_t todo = __ballot(ln != 0);
+            while (todo) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t lnj = (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)j), soj = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)j);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(temp + (size_t)(base + j) * CAP);
+                uint8_t *dst = post + soj;
+                if (4 * lane + 4 <= lnj) {
+                    const uint32_t x = src[lane];
+                    __builtin_memcpy(dst + 4 * lane, &x, 4);
+                } else if (4 * lane < lnj) {
+                    uint32_t x = src[lane];
+                    for (uint32_t q = 4 * lane; q < lnj; q++, x >>= 8) dst[q] = (uint8_t)x;
+                }
             }
-            so += w.len;
-            const uint32_t nx = w.next;
-            if (nx >= nids || nx % BZ_SUPER == 0) break;
-            id = nx;
         }
     }
     __threadfence_block();
@@ -1370,7 +1391,7 @@ extern "C" int semz_debug_bz_stamps(unsigned long long *out16, int reset)
 size_t semz_bzip2_scratch_per_block()
 {
     return sizeof(bz_meta) + (size_t)BZ_STRIDE * 2 + BZ_STRIDE * sizeof(uint32_t) + BZ_TEMP_STRIDE + BZ_SEGS * sizeof(bz_seg) +
-           BZ_IDS * sizeof(bz_row) + 2 * sizeof(uint32_t);
+           BZ_IDS * (sizeof(bz_row) + sizeof(uint2)) + 2 * sizeof(uint32_t) + 16;
 }
 
 int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
@@ -1385,9 +1406,11 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     const size_t segs_bytes = (size_t)nunits * BZ_SEGS * sizeof(bz_seg);
     const size_t rows_bytes = (size_t)nunits * BZ_IDS * sizeof(bz_row);
     const size_t ctl_bytes = 2 * (size_t)nunits * sizeof(uint32_t);
-    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, segs_bytes + rows_bytes + ctl_bytes, &segs))) return rc;
+    const size_t info_bytes = (size_t)nunits * BZ_IDS * sizeof(uint2);          // bz_link_kernel: two words per row
+    if ((rc = semz_scratch(c, SEMZ_SLOT_BZ_AUX, segs_bytes + rows_bytes + ((ctl_bytes + 15) & ~(size_t)15) + info_bytes, &segs))) return rc;
     bz_row *rows = (bz_row *)((uint8_t *)segs + segs_bytes);
     uint32_t *ctl = (uint32_t *)((uint8_t *)rows + rows_bytes);
+    uint2 *info = (uint2 *)((uint8_t *)ctl + ((ctl_bytes + 15) & ~(size_t)15));
     post = (uint8_t *)pre + (size_t)nunits * BZ_STRIDE;
     uint8_t *temp = (uint8_t *)tt + (size_t)nunits * BZ_STRIDE * sizeof(uint32_t);
     if (hipMemsetAsync(ctl, 0, ctl_bytes, c->stream) != hipSuccess) return semz_fail(c, -2, "hipMemsetAsync failed");
@@ -1404,7 +1427,7 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
     bz_walk_kernel<<<BZ_XCDS * WALK_WGS, WALK_THREADS, 0, c->stream>>>(nunits, (const bz_meta *)meta, (const uint32_t *)tt, temp, rows, ctl);
     semz_span_end(c);
     semz_span_begin(c, "bz_link_kernel");
-    bz_link_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (bz_meta *)meta, (uint8_t *)post, (bz_seg *)segs, temp, rows, ctl);
+    bz_link_kernel<<<nunits, BWT_THREADS, 0, c->stream>>>(nunits, (bz_meta *)meta, (uint8_t *)post, (bz_seg *)segs, temp, rows, ctl, info);
     semz_span_end(c);
     semz_span_begin(c, "bz_offsets_kernel");
     bz_offsets_kernel<<<1, OFFS_THREADS, 0, c->stream>>>(d_units, nunits, (bz_meta *)meta, out_cap, d_results, d_tails);
