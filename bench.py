@@ -27,10 +27,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # what the SQ counters (profiles/r01_*_pmc_sq.txt) say bounds the dominant kernel in practice
 ISSUE_NOTES = {
-    "gzip": "instruction-issue bound: scalar pipe 70 %, vector pipe 62 % of their issue rate (profiles/r01_gzip_pmc_sq.txt)",
-    "zlib": "instruction-issue bound like gzip, plus per-record table builds",
-    "bzip2": "bz_decode_kernel: latency of two serial waves per block; bz_bwt_kernel: one random HBM line per output byte, 81 % of wave cycles waiting on memory",
-    "xz": "serial range decoder: about 47 instructions and one LDS round trip per decoded bit, two waves per SIMD",
+    "gzip": "instruction-issue bound, the scalar unit first (four waves per SIMD share it): 6.8 wave-instructions per output byte, "
+            "2.79 G scalar + 3.48 G vector + 0.66 G branch + 0.42 G LDS per GiB (profiles/r02_gzip_pmc_sq.txt); traffic above "
+            "the algorithmic bytes is one 128-byte line per far match from the Infinity Cache (DESIGN.md section 3.1)",
+    "zlib": "instruction-issue bound like gzip, plus a table build per 4 KiB record",
+    "bzip2": "bz_decode_kernel: the latency of two serial waves per block (a 600-block batch is one wave per SIMD; 4800 blocks run at "
+             "12 blocks per CU and 2.8 times the rate); bz_walk_kernel: one dependent 4-byte read per output byte out of the XCD's L2",
+    "xz": "serial range decoder on the scalar unit: 25 instructions per decoded bit, 112 G scalar + 50 G vector instructions per "
+          "launch at one scalar instruction per 4.9 clocks and SIMD (the unit's limit is 4), two waves per SIMD",
 }
 METRIC = "decompressed GB/s (node) batched gzip/bzip2 blocks @1/2/4/8 GPUs; % HBM peak"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
