@@ -78,6 +78,7 @@
 (cffi:defcfun ("semz_last_error" semz-last-error) :string (ctx :pointer))
 (cffi:defcfun ("semz_strerror" semz-strerror) :string (status :int))
 (cffi:defcfun ("semz_set_option" semz-set-option) :int (ctx :pointer) (name :string) (value :long))
+(cffi:defcfun ("semz_get_option" semz-get-option) :int (ctx :pointer) (name :string) (value :pointer))
 (cffi:defcfun ("semz_stream_decode" semz-stream-decode) :int
   (ctx :pointer) (fmt :int) (in :pointer) (in-len :size) (all-members :int)
   (decoded :pointer) (res :pointer) (info :pointer))
@@ -112,6 +113,9 @@
   (:documentation "The engine itself failed (no GPU, HIP failure, API misuse). Never signalled for bad data:
 that is `semz.decompress:decompression-error', as in the reference."))
 
+(defvar *batch-budget* 0
+  "Device bytes a predicted batch may take (the engine's option \"batch-budget\"); a larger one is decoded window
+by window into host memory.  0 = three quarters of what the device has free when a call starts.")
 (defvar *engine* nil "The semz_ctx pointer, opened on first use.")
 
 (defun open-engine ()
@@ -129,7 +133,10 @@ signals `engine-error' (bind `*enabled*' to nil to use the reference's decoders)
             (unless (zerop rc)
               (error 'engine-error
                      :message (format nil "semz_open(~a) failed with ~d (no usable MI355X?)" *device* rc))))
-          (setf *engine* (cffi:mem-ref p :pointer))))))
+          (setf *engine* (cffi:mem-ref p :pointer))
+          (unless (zerop *batch-budget*)
+            (semz-set-option *engine* "batch-budget" *batch-budget*))
+          *engine*))))
 
 (defun close-engine ()
   (when *engine*
