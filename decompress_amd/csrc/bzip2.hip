@@ -1157,19 +1157,31 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
                     else if (so + ln > wlim) ln = wlim - so;
                 }
             }
+            // (eight rows in flight: with a row's store behind its load, one after the other, the copy was one
+            // memory latency per row, 1.9 ms of the kernel)
             uint64_t todo = __ballot(ln != 0);
             while (todo) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const uint32_t lnj = (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)j), soj = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)j);
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(temp + (size_t)(base + j) * CAP);
-                uint8_t *dst = post + soj;
-                if (4 * lane + 4 <= lnj) {
-                    const uint32_t x = src[lane];
-                    __builtin_memcpy(dst + 4 * lane, &x, 4);
-                } else if (4 * lane < lnj) {
-                    uint32_t x = src[lane];
-                    for (uint32_t q = 4 * lane; q < lnj; q++, x >>= 8) dst[q] = (uint8_t)x;
+                uint32_t x[8], lnv[8], sov[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const bool have = todo != 0;
+                    const uint32_t j = have ? (uint32_t)__builtin_ctzll(todo) : 0u;
+                    todo &= todo - (have ? 1 : 0);
+                    lnv[q] = have ? (uint32_t)__builtin_amdgcn_readlane((int)ln, (int)j) : 0u;
+                    sov[q] = (uint32_t)__builtin_amdgcn_readlane((int)so, (int)j);
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(temp + (size_t)(base + j) * CAP);
+                    x[q] = 4 * lane < lnv[q] ? src[lane] : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    uint8_t *dst = post + sov[q];
+                    // (no loop for the one to three bytes at a row's end: behind a loop the compiler waits for every
+                    // store before the next one)
+                    const uint32_t have = lnv[q] > 4 * lane ? lnv[q] - 4 * lane : 0u;
+                    if (have >= 4) __builtin_memcpy(dst + 4 * lane, &x[q], 4);
+                    if (have >= 1 && have < 4) dst[4 * lane] = (uint8_t)x[q];
+                    if (have >= 2 && have < 4) dst[4 * lane + 1] = (uint8_t)(x[q] >> 8);
+                    if (have == 3) dst[4 * lane + 2] = (uint8_t)(x[q] >> 16);
                 }
             }
         }
