@@ -364,7 +364,11 @@ def main():
                                   "path": "one semz_decode_stream_into call on pageable host buffers (input and a caller-owned, "
                                           "already touched output buffer): host split, H2D, kernels, D2H in four slices; never `value`"}
             # the same call with less device memory than the batch wants: window by window, two windows in flight
-            budget = a.batch_budget or (total_in + total_out) // 3
+            # (half of what the batch wants, decoder scratch included: windows a quarter of the batch each.  Much smaller
+            # windows starve the chip for bzip2 and xz, whose blocks take their tens and hundreds of milliseconds
+            # however few of them share it)
+            scratch = nun * 10_400_000 if a.format == "bzip2" else 0
+            budget = a.batch_budget or (total_in + total_out + scratch) // 2
             eng.set_option("batch-budget", budget)
             c_call()
             e2e_w = min(c_call(), c_call())
