@@ -128,6 +128,8 @@ extern "C" void semz_close(semz_ctx *c)
     for (auto &b : c->bufs) if (b.p) hipFree(b.p);
     for (auto &b : c->pool) hipFree(b.p);
     for (auto s : c->copy_streams) hipStreamDestroy(s);
+    for (auto e : c->aux_events) hipEventDestroy(e);
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->d_tabs) hipFree(c->d_tabs);
     hipStreamDestroy(c->stream);
     delete c;
@@ -158,6 +160,11 @@ extern "C" int semz_set_option(semz_ctx *c, const char *name, long value)
     }
     if (!strcmp(name, "lzma-honour-size")) { c->lz_honour_size = value != 0; return 0; }
     if (!strcmp(name, "lzma-no-fast")) { c->lz_no_fast = value != 0; return 0; }
+    if (!strcmp(name, "bzip2-overlap-blocks")) {
+        if (value < 0) return semz_fail(c, -1, "bzip2-overlap-blocks must not be negative");
+        c->bz_overlap_blocks = (uint32_t)value;
+        return 0;
+    }
     if (!strcmp(name, "bzip2-tables")) {
         if (value < 0 || value > 2) return semz_fail(c, -1, "bzip2-tables must be 0 (by batch size), 1 (narrow) or 2 (wide)");
         c->bz_tables = (int)value;

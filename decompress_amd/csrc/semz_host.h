@@ -31,6 +31,9 @@ struct semz_ctx {
     int lz_lc = -1, lz_lp = -1, lz_pb = -1, lz_eof_mode = 0;
     long long lz_size = -1;
     bool lz_honour_size = false;
+    uint32_t bz_overlap_blocks = 2048;  // option "bzip2-overlap-blocks": least blocks of a part of a large batch (0 = one piece)
+    hipStream_t aux_stream = nullptr;   // semz_run_bzip2: the inverse BWT of one part of a large batch beside the decode of the next
+    std::vector<hipEvent_t> aux_events;
     int bz_tables = 0;                  // option "bzip2-tables": 0 = by batch size, 1 = narrow root tables, 2 = wide (tests, measurements)
     bool lz_no_fast = false;            // option "lzma-no-fast": general kernel only (A/B measurements, tests of the general kernel)
     // semz_open_multi: contexts on the other devices; the stream calls spread a predicted batch over all of them

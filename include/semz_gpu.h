@@ -190,6 +190,8 @@ int semz_decode_batch_device_noalloc(semz_ctx *ctx, uint32_t kind, const void *d
  * "lzma-no-fast" = 1 decodes xz / LZMA2 units with the general kernel only (for measurements).
  * "bzip2-tables" = 1 / 2 decodes bzip2 blocks with the narrow / wide Huffman root tables whatever the batch
  * size (0, the default: wide up to 1024 blocks per call, narrow beyond; for tests and measurements).
+ * "bzip2-overlap-blocks" = the least number of blocks in a part of a large bzip2 batch (default 2048; a batch of
+ * at least two parts decodes one part beside the inverse BWT of the part before it; 0 = always one piece).
  * "batch-budget" = the device bytes (input, output, decoder scratch) a predicted batch of a stream call
  * may take; a larger one is decoded window by window into host memory -- straight into the caller's
  * buffer for semz_decode_stream_into -- with the upload of one window, the kernels of another and the

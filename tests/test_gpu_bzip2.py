@@ -147,3 +147,16 @@ def test_narrow_root_tables(engine):
     parts = [corpus.mixed(1500 + 37 * (i % 41), seed=i) for i in range(1100)]
     data = b"".join(bz2.compress(p, 1) for p in parts)
     check_stream(engine, data, 1, b"".join(parts), cap=1 << 22)
+
+
+def test_batch_in_parts(engine):
+    """A large batch goes in parts, the decode of one beside the inverse BWT of the one before it on a second stream
+    (semz_run_bzip2); the option makes parts of 16 blocks so that a batch of this size takes that road, four parts."""
+    parts = [corpus.mixed(20000 + 977 * (i % 23), seed=300 + i) for i in range(70)] + [corpus.repetitive(150000, seed=9)]
+    data = b"".join(bz2.compress(p, 1) for p in parts)
+    engine.set_option("bzip2-overlap-blocks", 16)
+    try:
+        for _ in range(2):                                        # (twice: the second call meets the scratch of the first)
+            check_stream(engine, data, 1, b"".join(parts), cap=1 << 22)
+    finally:
+        engine.set_option("bzip2-overlap-blocks", 2048)
