@@ -48,6 +48,7 @@ constexpr int BZ_CHAINS = 16384;               // inverse-BWT chain starts per b
 constexpr int BZ_IDS = 20608;                  // 16386 markers + 4098 continuations at the most, and some
 constexpr int BZ_SUPER = 16;                   // bz_link_kernel: every 16th id heads a run of rows
 constexpr size_t BZ_TEMP_STRIDE = 5 * (size_t)900032 + 65536;
+constexpr int LINK_DEPTH = 16;                 // bz_link_kernel: rows a wave has in flight while it copies
 constexpr int BWT_THREADS = 512;               // bz_sort_kernel, bz_link_kernel: one workgroup per block
 constexpr int BWT_WAVES = BWT_THREADS / 64;
 // bz_walk_kernel: the chip's eight XCDs (one L2 each) take the blocks in turn, so that the one vector an XCD is
@@ -1156,13 +1157,13 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
                     else if (so + ln > wlim) ln = wlim - so;
                 }
             }
-            // (eight rows in flight: with a row's store behind its load, one after the other, the copy was one
+            // (LINK_DEPTH rows in flight: with a row's store behind its load, one after the other, the copy was one
             // memory latency per row, 1.9 ms of the kernel)
             uint64_t todo = __ballot(ln != 0);
             while (todo) {
-                uint32_t x[8], lnv[8], sov[8];
+                uint32_t x[LINK_DEPTH], lnv[LINK_DEPTH], sov[LINK_DEPTH];
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
+                for (int q = 0; q < LINK_DEPTH; q++) {
                     const bool have = todo != 0;
                     const uint32_t j = have ? (uint32_t)__builtin_ctzll(todo) : 0u;
                     todo &= todo - (have ? 1 : 0);
@@ -1172,7 +1173,7 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_link_kernel(uint32_t nunits, b
                     x[q] = 4 * lane < lnv[q] ? src[lane] : 0u;
                 }
 #pragma unroll
-                for (int q = 0; q < 8; q++) {
+                for (int q = 0; q < LINK_DEPTH; q++) {
                     uint8_t *dst = post + sov[q];
                     // (no loop for the one to three bytes at a row's end: behind a loop the compiler waits for every
                     // store before the next one)
