@@ -318,7 +318,9 @@ struct Run {
             while (c->lanes.size() < 2) {
                 semz_ctx *l = nullptr;
                 if (semz_open(c->device, &l)) return semz_fail(c, -2, "batch loop: no further context on device %d", c->device);
-                l->lz_no_fast = c->lz_no_fast;
+                l->lz_no_fast = c->lz_no_fast;                        // (options set before the lanes existed)
+                l->bz_tables = c->bz_tables;
+                l->bz_overlap_blocks = c->bz_overlap_blocks;
                 c->lanes.push_back(l);
             }
             for (semz_ctx *l : c->lanes) {
