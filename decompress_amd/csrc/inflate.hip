@@ -45,7 +45,9 @@
 #ifdef SEMZ_STAMPS
 // diagnostic build only (make STAMPS=1): per-phase shader-clock totals summed over all units
 __device__ unsigned long long g_stamps[16];
-#define STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0}; uint32_t n_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// per unit (the first 16384 of a launch): start and end on the constant 100 MHz clock, and where the wave ran (HW_ID)
+__device__ unsigned long long g_unit_times[16384][3];
+#define STAMP_DECL const uint64_t t_unit0 = __builtin_amdgcn_s_memrealtime(); uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[6] = {0, 0, 0, 0, 0, 0}; uint32_t n_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define COUNT(i, n) do { n_acc[i] += (n); } while (0)
 #else
@@ -59,6 +61,7 @@ namespace {
 constexpr int LIT_ROOT_BITS = 10;
 constexpr int DIST_ROOT_BITS = 8;
 constexpr int CLEN_ROOT_BITS = 7;
+constexpr int PRIO_TURN_SHIFT = 11;      // a turn at a priority lasts 2^11 ticks of the 100 MHz clock, 20 us
 constexpr int RING = 4096;               // output staging ring (bytes)
 constexpr int RING_MASK = RING - 1;
 constexpr int ROUND_BYTES = 2048;        // a round stops once it has produced this many bytes
@@ -487,7 +490,18 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
 
     STAMP_DECL
     // ---- main loop: one round per iteration ----
+    // The arbiter of a SIMD takes the oldest wave that is ready, so of four units that share a SIMD one runs ahead
+    // and the last one ends alone, on a quarter of the issue rate (scripts/inflate_unit_times.py: the four units of
+    // a SIMD ended 2.6 ms apart, of 9.9).  The waves therefore take turns at the priorities, by the clock and their
+    // slot on the SIMD, and end together.
+    const uint32_t prio_slot = __builtin_amdgcn_s_getreg((4 << 11) | 4);          // HW_ID: wave slot, bits 3:0
     for (;;) {
+        switch (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> PRIO_TURN_SHIFT) + prio_slot) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
         STAMP(5);
         // scripts/check_uniform.sh: without this pin the optimiser's merge of P behind the lane-masked stores of the
         // round counts as divergent and the whole decoder state moves to VGPRs
@@ -1083,6 +1097,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 for (int i = 0; i < 6; i++) atomicAdd(&g_stamps[i], (unsigned long long)t_acc[i]);
                 for (int i = 0; i < 8; i++) atomicAdd(&g_stamps[6 + i], (unsigned long long)n_acc[i]);
                 atomicAdd(&g_stamps[14], 1ull);
+                if (u < 16384) {
+                    g_unit_times[u][0] = t_unit0;
+                    g_unit_times[u][1] = __builtin_amdgcn_s_memrealtime();
+                    g_unit_times[u][2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                }
 #endif
             }
             break;
@@ -1101,6 +1120,13 @@ extern "C" int semz_debug_stamps(unsigned long long *out16, int reset)
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;
+}
+#endif
+
+#ifdef SEMZ_STAMPS
+extern "C" int semz_debug_unit_times(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_unit_times), (size_t)n * 24) == hipSuccess ? 0 : -1;
 }
 #endif
 
