@@ -61,7 +61,7 @@ namespace {
 constexpr int LIT_ROOT_BITS = 10;
 constexpr int DIST_ROOT_BITS = 8;
 constexpr int CLEN_ROOT_BITS = 7;
-constexpr int PRIO_TURN_SHIFT = 11;      // a turn at a priority lasts 2^11 ticks of the 100 MHz clock, 20 us
+constexpr int PRIO_TURN_SHIFT = 14;      // a turn at a priority lasts 2^14 ticks of the 100 MHz clock, 164 us (5 us: 9.35 ms; 20 us: 8.86; 164 and 655 us: 8.81; 2.6 ms: 9.01)
 constexpr int RING = 4096;               // output staging ring (bytes)
 constexpr int RING_MASK = RING - 1;
 constexpr int ROUND_BYTES = 2048;        // a round stops once it has produced this many bytes
@@ -490,18 +490,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
 
     STAMP_DECL
     // ---- main loop: one round per iteration ----
-    // The arbiter of a SIMD takes the oldest wave that is ready, so of four units that share a SIMD one runs ahead
-    // and the last one ends alone, on a quarter of the issue rate (scripts/inflate_unit_times.py: the four units of
-    // a SIMD ended 2.6 ms apart, of 9.9).  The waves therefore take turns at the priorities, by the clock and their
-    // slot on the SIMD, and end together.
-    const uint32_t prio_slot = __builtin_amdgcn_s_getreg((4 << 11) | 4);          // HW_ID: wave slot, bits 3:0
     for (;;) {
-        switch (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> PRIO_TURN_SHIFT) + prio_slot) & 3) {
-        case 0: __builtin_amdgcn_s_setprio(0); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        default: __builtin_amdgcn_s_setprio(3); break;
-        }
+        semz_take_turn(PRIO_TURN_SHIFT);         // (semz_device.h: the units of a SIMD end together)
         STAMP(5);
         // scripts/check_uniform.sh: without this pin the optimiser's merge of P behind the lane-masked stores of the
         // round counts as divergent and the whole decoder state moves to VGPRs

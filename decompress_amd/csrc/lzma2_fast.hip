@@ -333,6 +333,7 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     bool ok = true;                 // false: hand the unit to the general kernel
 
     auto flush = [&](bool all) {
+        semz_take_turn(16);                      // (semz_device.h: the two units of a SIMD end together; 0.65 ms a turn)
         const uint32_t head = (16 - shift) & 15;
         if (flushed == 0 && head && (p >= head || all)) {
             const uint32_t n = p < head ? p : head;
