@@ -479,6 +479,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 }
                 if (k == (uint32_t)BZ_GROUP) {
                     if (g >= nsel) BZ_FAIL(SEMZ_E_BZ_SELECTORS_EXHAUSTED, 0);
+                    if ((g & 31) == 0) semz_take_turn(15);               // (semz_device.h; every 1600 symbols)
                     if ((g >> 9) != selblk) {
                         selblk = g >> 9;
                         selw = __hip_atomic_load(selg + 64 * selblk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -643,6 +644,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 if (m == 0) break;                                       // done and drained
                 const uint32_t sq = (uint32_t)lane < m ? L.symq[(consumed + lane) & (BZ_QCAP - 1)] : 0u;
                 consumed += m;
+                if ((consumed & 2047) < 64) semz_take_turn(15);          // (semz_device.h; every 2048 symbols)
                 const uint64_t validm = m == 64 ? ~0ull : (1ull << m) - 1;
                 const uint64_t bmask = __builtin_amdgcn_ballot_w64(sq == 1) & validm;
                 const uint64_t mtfmask = __builtin_amdgcn_ballot_w64(sq >= 2) & validm;
