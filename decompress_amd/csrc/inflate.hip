@@ -61,7 +61,7 @@ namespace {
 constexpr int LIT_ROOT_BITS = 10;
 constexpr int DIST_ROOT_BITS = 8;
 constexpr int CLEN_ROOT_BITS = 7;
-constexpr int PRIO_TURN_SHIFT = 14;      // a turn at a priority lasts 2^14 ticks of the 100 MHz clock, 164 us (5 us: 9.35 ms; 20 us: 8.86; 164 and 655 us: 8.81; 2.6 ms: 9.01)
+constexpr int PRIO_TURN_SHIFT = 14;      // a turn at a priority lasts 2^14 ticks of the 100 MHz clock, 164 us (asked every round: 5 us 9.35 ms; 20 us 8.86; 164 and 655 us 8.81; 2.6 ms 9.01)
 constexpr int RING = 4096;               // output staging ring (bytes)
 constexpr int RING_MASK = RING - 1;
 constexpr int ROUND_BYTES = 2048;        // a round stops once it has produced this many bytes
@@ -491,7 +491,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
     STAMP_DECL
     // ---- main loop: one round per iteration ----
     for (;;) {
-        semz_take_turn(PRIO_TURN_SHIFT);         // (semz_device.h: the units of a SIMD end together)
+        // (semz_device.h: the units of a SIMD end together.  A record of a few kilobytes never asks)
+        if (pos >= 8192) semz_take_turn(PRIO_TURN_SHIFT);
         STAMP(5);
         // scripts/check_uniform.sh: without this pin the optimiser's merge of P behind the lane-masked stores of the
         // round counts as divergent and the whole decoder state moves to VGPRs
