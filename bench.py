@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # what the SQ counters (profiles/r01_*_pmc_sq.txt) say bounds the dominant kernel in practice
 ISSUE_NOTES = {
-    "gzip": "instruction-issue bound, the scalar unit first (four waves per SIMD share it): 6.8 wave-instructions per output byte, "
+    "gzip": "instruction-issue bound, the scalar unit first (four waves per SIMD share it and take turns at its priorities): 6.8 wave-instructions per output byte, "
             "2.79 G scalar + 3.48 G vector + 0.66 G branch + 0.42 G LDS per GiB (profiles/r02_gzip_pmc_sq.txt); traffic above "
             "the algorithmic bytes is one 128-byte line per far match from the Infinity Cache (DESIGN.md section 3.1)",
     "zlib": "instruction-issue bound like gzip, plus a table build per 4 KiB record",
