@@ -208,3 +208,32 @@ def test_sizes_that_lie_under_a_tight_budget():
         lies.test_block_header_sizes_that_lie(eng)
     finally:
         eng.close()
+
+
+def test_windows_on_the_devices_of_a_multi_context(engines):
+    """semz_open_multi + a tight budget: the helper devices are lanes of the batch loop beside the two of the primary
+    device (the box has one GPU, so it is named three times)."""
+    whole, _ = engines
+    eng = _lib.Engine([0, 0, 0])
+    eng.set_option("batch-budget", 3 << 20)
+    try:
+        plain = _members(48, 200 * 1024, 700)
+        blobs = [bytearray(gzip.compress(p, 6)) for p in plain]
+        data = b"".join(bytes(b) for b in blobs)
+        want = _decode(whole, _lib.FMT_GZIP, data)
+        assert want[0] == 0 and want[3] == b"".join(plain)
+        assert _decode(eng, _lib.FMT_GZIP, data) == want and eng.get_option("windows") >= 6
+        blobs[40][len(blobs[40]) // 2] ^= 0x55
+        data = b"".join(bytes(b) for b in blobs)
+        want = _decode(whole, _lib.FMT_GZIP, data)
+        assert want[0] != 0 and want[3] == b"".join(plain[:40])
+        assert _decode(eng, _lib.FMT_GZIP, data) == want
+        rc, st, det, end, out, n = _into(eng, _lib.FMT_GZIP, data, len(want[3]) + (1 << 20))
+        assert (rc, st, det, end, out) == (0, want[0], want[1], want[2], want[3])
+        big = corpus.text(5 * (1 << 20), seed=70)
+        data = bz2.compress(big, 1)
+        eng.set_option("batch-budget", 96 << 20)
+        assert _decode(eng, _lib.FMT_BZIP2, data) == _decode(whole, _lib.FMT_BZIP2, data)
+        assert eng.get_option("windows") >= 4
+    finally:
+        eng.close()
