@@ -855,9 +855,15 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_sort_kernel(uint32_t nunits, c
             const uint32_t i = b0 + 64 * q + lane;
             v[q] = i < cend ? pre[i] : 0x100u;
         }
+        // (this is the last column of a BWT: the 64 bytes of a piece are more often than not one and the same, and
+        // 64 atomics on one counter take their turns)
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            if (v[q] < 0x100u) atomicAdd(&hist[wave * 256 + v[q]], 1u);
+        for (int q = 0; q < 8; q++) {
+            const uint32_t v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v[q]);
+            if (__ballot(v[q] != v0) == 0) {
+                if (lane == 0 && v0 < 0x100u) atomicAdd(&hist[wave * 256 + v0], 64u);
+            } else if (v[q] < 0x100u) atomicAdd(&hist[wave * 256 + v[q]], 1u);
+        }
     }
     __syncthreads();
     // ---- 2. prefix sums: cumm[v] (bzip2.lisp:150-151) and each wave's base per byte value ----
@@ -890,10 +896,12 @@ __global__ __launch_bounds__(BWT_THREADS) void bz_sort_kernel(uint32_t nunits, c
             const bool valid = i < cend;
             const uint32_t v = vq[q];
             uint64_t same = __ballot(valid);
+            if (__ballot(!valid || v != (uint32_t)__builtin_amdgcn_readfirstlane((int)v)) != 0) {    // (not all the same byte)
 #pragma unroll
-            for (int bit = 0; bit < 8; bit++) {
-                uint64_t bm = __ballot((v >> bit) & 1);
-                same &= ((v >> bit) & 1) ? bm : ~bm;
+                for (int bit = 0; bit < 8; bit++) {
+                    uint64_t bm = __ballot((v >> bit) & 1);
+                    same &= ((v >> bit) & 1) ? bm : ~bm;
+                }
             }
             const uint32_t rank = __popcll(same & ((1ull << lane) - 1));
             const uint32_t cnt = __popcll(same);
