@@ -100,8 +100,8 @@ int main()
     unsigned long long *d, h[1];
     hipMalloc(&d, 16384);
     const int iters = 50000;
-    const int grids[3] = {1, 1024, 2048};         // one wave alone; one wave on every SIMD; two
-    for (int gi = 0; gi < 3; gi++) {
+    const int grids[5] = {1, 1024, 2048, 4096, 8192};   // one wave alone; one, two, four, eight waves on every SIMD
+    for (int gi = 0; gi < 5; gi++) {
         int g = grids[gi];
 #define RUN(k, what, n) do { k<<<g, 64>>>(d, iters); hipDeviceSynchronize(); k<<<g, 64>>>(d, iters); hipDeviceSynchronize(); \
         hipMemcpy(h, d, 8, hipMemcpyDeviceToHost); printf("grid %4d %-44s %7.2f ticks per instruction\n", g, what, (double)h[0] / (16.0 * iters * (n))); fflush(stdout); } while (0)
