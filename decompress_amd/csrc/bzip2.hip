@@ -514,15 +514,18 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                     // lane holds a length of at least 1: the trees are complete (bz_build_tree).  The s_nop is the
                     // wait state gfx950 wants between the VALU write of lenv and a v_readlane of it.
                     uint32_t offb = 0u - 64u, len;
+                    // (eight steps written out between two jumps back: a taken branch costs three times what a
+                    // branch that falls through does, and this wave has its SIMD to itself in a batch of 600 blocks)
+#define BZ_CHAIN_STEP "v_readlane_b32 %[t], %[tb], %[off]\n\ts_bitset1_b64 %[m], %[off]\n\ts_add_u32 %[off], %[off], %[t]\n\ts_cbranch_scc1 2f\n\t"
                     asm volatile("s_nop 0\n"
                                  "1:\n\t"
-                                 "v_readlane_b32 %[t], %[tb], %[off]\n\t"
-                                 "s_bitset1_b64 %[m], %[off]\n\t"
-                                 "s_add_u32 %[off], %[off], %[t]\n\t"
-                                 "s_cbranch_scc0 1b"
+                                 BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP BZ_CHAIN_STEP
+                                 "s_branch 1b\n"
+                                 "2:"
                                  : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(len)
                                  : [tb] "v"(lenv)
                                  : "scc");
+#undef BZ_CHAIN_STEP
                     off = offb + 64u;
                 } else {
                     // the last bits of the input: the reference runs out of data when fewer bits than the
