@@ -691,13 +691,20 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 uint32_t xv = 0;
                 if (__builtin_amdgcn_ballot_w64(idxv >= 64) == 0) {
                     // every index of the batch lies inside the register: a loop without any other path
-                    for (uint32_t e = 0; e < cnt; e++) {
+                    // (four symbols between two jumps back, the byte put into its lane with one v_writelane: this
+                    // loop is the wave's chain, 900 k times per block)
+                    auto step = [&](uint32_t e) {
                         const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
                         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
                         const uint32_t sh = shr1(mtf_a, x);
                         mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
-                        xv = (uint32_t)lane == e ? x : xv;
-                    }
+                        // (x comes out of a v_readlane: the wait states between a VALU write of an SGPR and its use
+                        // by a lane instruction are written out, nobody inserts them inside an asm statement)
+                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(xv) : "s"(x), "s"(e) : "m0");
+                    };
+                    uint32_t e = 0;
+                    for (; e + 4 <= cnt; e += 4) { step(e); step(e + 1); step(e + 2); step(e + 3); }
+                    for (; e < cnt; e++) step(e);
                 } else {
                     for (uint32_t e = 0; e < cnt; e++) {
                         const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
