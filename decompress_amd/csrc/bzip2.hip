@@ -703,7 +703,8 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                         asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(xv) : "s"(x), "s"(e) : "m0");
                     };
                     uint32_t e = 0;
-                    for (; e + 4 <= cnt; e += 4) { step(e); step(e + 1); step(e + 2); step(e + 3); }
+                    for (; e + 8 <= cnt; e += 8) { step(e); step(e + 1); step(e + 2); step(e + 3); step(e + 4); step(e + 5); step(e + 6); step(e + 7); }
+                    for (; e + 2 <= cnt; e += 2) { step(e); step(e + 1); }
                     for (; e < cnt; e++) step(e);
                 } else {
                     for (uint32_t e = 0; e < cnt; e++) {
