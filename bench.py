@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--no-spans", action="store_true",
                     help="time the steps without the per-kernel event pairs (large bzip2 batches overlap kernels on two streams "
                          "only then); the roofline object then speaks of the whole step")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option for the run (semz_set_option)")
     ap.add_argument("--batch-budget", type=int, default=0,
                     help="end-to-end call: device bytes a batch may take (the library's option of that name); a smaller "
                          "value than the workload needs makes the call decode window by window")
@@ -261,6 +262,9 @@ def main():
         dist.init_process_group("gloo")
 
     eng = _lib.Engine(local)
+    for kv in a.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
     d_in = eng.dev_alloc(total_in + 64)
     d_units = eng.dev_alloc(C.sizeof(uarr))
     d_out = eng.dev_alloc(W["out_cap"] + 64)

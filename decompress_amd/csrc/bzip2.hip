@@ -1049,7 +1049,10 @@ __global__ __launch_bounds__(WALK_THREADS) void bz_walk_kernel(uint32_t nunits, 
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0));
                 if (rank < room) {
                     const uint32_t c = next + rank;
-                    active = true;
+                    // (when origPtr is a marker position the marker's own chain would be a twin of chain 0 that nothing
+                    // links to; it is not walked: its rows, and above all the rows it would go on in under ids handed
+                    // out at run time, must not exist for bz_link_kernel to come across)
+                    active = c == 0 || (c - 1) * c_S != c_orig;
                     blk = cur;
                     nmark = c_nmark;
                     smask = c_S - 1;
