@@ -86,6 +86,7 @@ struct Run {
     std::vector<uint8_t> distrust;             // per unit of the last decode(): the result must not be used (see multi.h)
     std::vector<uint64_t> cand;                // gzip: member-start candidates found while the input was on its way up
     bool cand_ready = false;
+    std::vector<BzCandidate> bz_cand;          // bzip2: the magics, found while the input was on its way up
 
     ~Run()
     {
@@ -839,7 +840,7 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
 // ---- bzip2 ----
 int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
 {
-    std::vector<BzCandidate> cand = scan_bzip2(R.in, R.in_len);
+    std::vector<BzCandidate> cand = R.cand_ready ? std::move(R.bz_cand) : scan_bzip2(R.in, R.in_len);
     std::vector<semz_unit> units;
     std::vector<uint64_t> start_bits;
     uint64_t guess = 0;
@@ -1226,6 +1227,8 @@ static int stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len,
     std::thread scanner;
     if (fmt == SEMZ_FMT_GZIP && all_members && in_len >= (1u << 20))
         scanner = std::thread([&R, in, in_len] { R.cand = scan_gzip_candidates(in, in_len); });
+    else if (fmt == SEMZ_FMT_BZIP2 && in_len >= (1u << 20))
+        scanner = std::thread([&R, in, in_len] { R.bz_cand = scan_bzip2(in, in_len); });
     int rc = R.open();
     if (scanner.joinable()) {
         scanner.join();
