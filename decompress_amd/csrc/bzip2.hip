@@ -1488,14 +1488,6 @@ int semz_run_bzip2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
         semz_span_end(c);
         bwt(0, nunits, c->stream, true);
     } else {
-        if (!c->aux_stream) {
-            // (at the highest priority: the part that is ahead gets the CU resources as the decode's blocks retire,
-            // instead of waiting behind a grid that can fill the chip by itself)
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, greatest) != hipSuccess)
-                return semz_fail(c, -2, "hipStreamCreate failed");
-        }
         while (c->aux_events.size() < parts + 1) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return semz_fail(c, -2, "hipEventCreate failed");

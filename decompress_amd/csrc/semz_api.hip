@@ -78,6 +78,16 @@ extern "C" int semz_open(int device, semz_ctx **out)
     semz_ctx *c = new semz_ctx();
     c->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return -2; }
+    // The second stream of semz_run_bzip2 (the inverse BWT of one part of a large batch beside the decode of the
+    // next).  At the default priority and created here, not on first use: created at the highest priority once the
+    // download streams of the stream calls existed (more streams than the 4 hardware queues of a process), the event
+    // hand-over between the two streams never completed -- a 4800-block batch after one gzip stream call hung.  The
+    // priority was worth nothing measurable (28.0 GB/s on that batch either way).
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamDestroy(c->stream);
+        delete c;
+        return -2;
+    }
     semz_check_tables *h = new semz_check_tables();
     semz_build_check_tables(h);
     hipError_t e = hipMalloc((void **)&c->d_tabs, sizeof(semz_check_tables));
@@ -86,6 +96,7 @@ extern "C" int semz_open(int device, semz_ctx **out)
     if (e == hipSuccess) e = hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch));   // this device's copy
     if (e != hipSuccess || !c->noalloc_scratch) {
         if (c->d_tabs) hipFree(c->d_tabs);
+        hipStreamDestroy(c->aux_stream);
         hipStreamDestroy(c->stream);
         delete c;
         return -2;

@@ -181,3 +181,47 @@ def test_origptr_on_a_marker_position(engine):
         out, res = engine.decode_batch(data, units, len(want))
         assert [r.status for r in res] == [0] * len(units)
         assert out.raw[:len(want)] == want
+
+
+def test_default_road_beyond_4096_blocks(engine):
+    """The road a batch of BASELINE configs[2]'s size takes by itself: more than 4096 blocks, so narrow root tables
+    chosen automatically and two parts on two streams (the decode of one part beside the inverse BWT of the other),
+    after a stream call whose download has created the context's copy streams -- with more streams than hardware
+    queues the second stream of semz_run_bzip2, then created on first use at the highest priority, never saw the
+    first one's events and the 4800-block bench hung (round 3).  66 streams of 64 blocks of 100 k, replicated from
+    four distinct ones; every status, every block's size and CRC against the streams' own, the first and the last
+    stream's bytes."""
+    import zlib
+    big = corpus.text(40 << 20, seed=4096)                        # a download of 32 MiB and more goes in four slices
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    gz = co.compress(big) + co.flush()
+    got, r, _ = engine.decode_stream(_lib.FMT_GZIP, gz, True)
+    assert r.status == 0 and got == big
+    del got, big
+    plains = [corpus.text(6_400_000 - 1000 * i, seed=9000 + i) for i in range(4)]
+    streams = [bz2.compress(p, 1) for p in plains]
+    per = [block_units(s, 1) for s in streams]
+    order = [i % 4 for i in range(66)]
+    data = b"".join(streams[i] for i in order)
+    units, off = [], 0
+    for i in order:
+        for u in per[i]:
+            units.append(_lib.Unit(in_off=off + u.in_off, in_bit_off=u.in_bit_off, in_limit=len(data), out_off=_lib.OUT_AUTO,
+                                   out_cap=0, kind=_lib.UNIT_BZIP2_BLOCK, param0=1))
+        off += len(streams[i])
+    assert len(units) > 4096
+    total = sum(len(plains[i]) for i in order)
+    for _ in range(2):
+        out, res = engine.decode_batch(data, units, total)
+        assert [r.status for r in res] == [0] * len(units)
+        assert sum(r.out_len for r in res) == total
+        assert out.raw[:len(plains[0])] == plains[0]
+        assert out.raw[total - len(plains[order[-1]]):total] == plains[order[-1]]
+        # every copy of a stream decodes to the same blocks
+        k = 0
+        first = {}
+        for i in order:
+            for j in range(len(per[i])):
+                sig = (res[k].out_len, bytes(res[k].check[:4]))
+                assert first.setdefault((i, j), sig) == sig
+                k += 1
