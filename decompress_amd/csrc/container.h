@@ -46,6 +46,8 @@ uint64_t read_bits_be(const uint8_t *in, uint64_t in_len, uint64_t bit, unsigned
 struct XzBlockHeader {
     int status = SEMZ_OK;
     uint32_t detail = 0;
+    uint32_t detail2 = 0;             // second argument of the reference's message: the computed header CRC
+                                      // (xz.lisp:404-405), the alignment the BCJ offset misses (xz.lisp:342)
     uint64_t header_size = 0;         // bytes including the size byte, excluding the CRC-32
     bool have_csize = false, have_usize = false;
     uint64_t csize = 0, usize = 0;

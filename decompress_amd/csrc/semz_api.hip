@@ -56,6 +56,8 @@ extern "C" int semz_profile_get(semz_ctx *c, int i, const char **name, float *ms
 extern "C" void semz_profile_reset(semz_ctx *c)
 {
     if (!c) return;
+    for (semz_ctx *h : c->helpers) semz_profile_reset(h);      // (spans recorded by the other devices and by the lanes
+    for (semz_ctx *h : c->lanes) semz_profile_reset(h);        // of the batch loop while "profile" was on)
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     c->spans.clear();
 }
@@ -129,6 +131,7 @@ extern "C" int semz_device_count(const semz_ctx *c) { return c ? 1 + (int)c->hel
 extern "C" void semz_close(semz_ctx *c)
 {
     if (!c) return;
+    semz_stream_orphan_all(c);
     for (semz_ctx *h : c->helpers) semz_close(h);
     c->helpers.clear();
     for (semz_ctx *h : c->lanes) semz_close(h);
@@ -202,6 +205,7 @@ extern "C" int semz_get_option(semz_ctx *c, const char *name, long *value)
 
 hipError_t semz_pool_take(semz_ctx *c, size_t bytes, void **p, size_t *cap)
 {
+    std::lock_guard<std::mutex> g(c->mu);
     size_t best = SIZE_MAX;
     for (size_t i = 0; i < c->pool.size(); i++)
         if (c->pool[i].cap >= bytes && c->pool[i].cap / 2 <= bytes && (best == SIZE_MAX || c->pool[i].cap < c->pool[best].cap)) best = i;
@@ -225,6 +229,7 @@ hipError_t semz_pool_take(semz_ctx *c, size_t bytes, void **p, size_t *cap)
 void semz_pool_give(semz_ctx *c, void *p, size_t cap)
 {
     if (!p) return;
+    std::lock_guard<std::mutex> g(c->mu);
     c->pool.push_back(semz_devbuf{p, cap});
     if (c->pool.size() > SEMZ_POOL_MAX) {
         size_t small = 0;
@@ -311,7 +316,7 @@ extern "C" int semz_decode_batch_device_noalloc(semz_ctx *c, uint32_t kind, cons
                                 "per-batch scratch: use semz_decode_batch_device)", kind);
     if (nunits > SEMZ_NOALLOC_MAX_UNITS)
         return semz_fail(c, -1, "semz_decode_batch_device_noalloc takes at most %zu units per call (got %zu): split the batch",
-                         SEMZ_NOALLOC_MAX_UNITS, nunits);
+                         (size_t)SEMZ_NOALLOC_MAX_UNITS, nunits);
     HIPCHK(c, hipSetDevice(c->device));
     semz_tail *tails = (semz_tail *)c->noalloc_scratch;          // the device address, never the symbol's name
     // the array keeps the last call's contents: the records of this call start from zero

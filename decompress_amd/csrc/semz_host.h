@@ -1,6 +1,7 @@
 // semz_host.h -- host-side internals of the library (context, kernel launchers).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <vector>
 #include "semz_device.h"
 
@@ -52,6 +53,11 @@ struct semz_ctx {
     uint64_t last_moved = 0;            // pieces of such windows the last read found out of place in the caller's buffer ("moved")
     // further streams for downloads of large results in parallel slices (created on first use)
     std::vector<hipStream_t> copy_streams;
+    // Decoded streams that live on this context (semz_stream_decode): semz_close takes their device memory back and
+    // cuts them loose, so that a release that comes after the close (a finalizer, a destructor) touches no context.
+    // `mu` guards this list and the pool: a release may come from another thread than the one that decodes.
+    std::vector<struct semz_decoded *> live;
+    std::mutex mu;
     struct span { const char *name; hipEvent_t a, b; };
     std::vector<span> spans;
     char err[512] = {0};
@@ -64,7 +70,9 @@ enum {
     SEMZ_SLOT_COUNT
 };
 
-int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...);
+int semz_fail(semz_ctx *ctx, int rc, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+// semz_close: the decoded streams still alive on `c` give their device memory back and forget the context
+void semz_stream_orphan_all(semz_ctx *c);
 // RAII-less helpers: bracket a kernel (or kernel sequence) with events when profiling
 void semz_span_begin(semz_ctx *c, const char *name);
 void semz_span_end(semz_ctx *c);

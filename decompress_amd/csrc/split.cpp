@@ -217,7 +217,7 @@ XzBlockHeader parse_xz_block_header(const uint8_t *in, uint64_t pos, uint64_t in
     if (in_len - pos < hlen + 4) return fail(SEMZ_EOF, 0);
     const uint8_t *hdr = in + pos;
     const uint32_t crc = (uint32_t)hdr[hlen] | ((uint32_t)hdr[hlen + 1] << 8) | ((uint32_t)hdr[hlen + 2] << 16) | ((uint32_t)hdr[hlen + 3] << 24);
-    if (crc != crc32_host(hdr, hlen)) return fail(SEMZ_E_XZ_BLOCK_HDR_CRC, crc);
+    if (crc != crc32_host(hdr, hlen)) { h.detail2 = crc32_host(hdr, hlen); return fail(SEMZ_E_XZ_BLOCK_HDR_CRC, crc); }
     // handle-xz-block, xz.lisp:260-379
     const uint32_t flags = hdr[1], nfilters = 1 + (flags & 3);
     if ((flags >> 2) & 15) return fail(SEMZ_E_XZ_BLOCK_RESERVED, 0);
@@ -258,7 +258,7 @@ XzBlockHeader parse_xz_block_header(const uint8_t *in, uint64_t pos, uint64_t in
             uint32_t off = 0;
             if (pl == 4) off = (uint32_t)pp[0] | ((uint32_t)pp[1] << 8) | ((uint32_t)pp[2] << 16) | ((uint32_t)pp[3] << 24);
             else if (pl != 0) return fail(SEMZ_E_XZ_BCJ_PROPS, (uint32_t)pl);
-            if (off % align[id - 4]) return fail(SEMZ_E_XZ_BCJ_ALIGN, off);
+            if (off % align[id - 4]) { h.detail2 = align[id - 4]; return fail(SEMZ_E_XZ_BCJ_ALIGN, off); }
             // semz_unit has one start offset: a second BCJ stage with another offset is not representable
             if (have_bcj && off != h.bcj_offset) return fail(SEMZ_E_UNSUPPORTED, (uint32_t)id);
             have_bcj = true;

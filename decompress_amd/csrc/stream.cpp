@@ -90,11 +90,23 @@ struct Run {
 
     ~Run()
     {
+        free_device();
+        for (auto &k : chunks)
+            if (k.owned) free(k.p);
+    }
+    // Everything the Run holds on its devices goes back; the Run forgets its context (semz_close calls this for
+    // the decoded streams that outlive their context: nothing may touch the context after that).
+    void free_device()
+    {
+        if (!c) return;
+        (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         semz_pool_give(c, d_in, d_in_cap);
         semz_pool_give(c, d_out, out_cap);
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
+        d_in = d_out = nullptr; d_units = nullptr; d_res = nullptr;
+        d_in_cap = out_cap = unit_cap = 0;
         for (auto &h : helpers) {
             (void)hipSetDevice(h.c->device);
             (void)hipStreamSynchronize(h.c->stream);
@@ -105,8 +117,8 @@ struct Run {
         }
         release_lanes();
         if (!helpers.empty()) (void)hipSetDevice(c->device);
-        for (auto &k : chunks)
-            if (k.owned) free(k.p);
+        helpers.clear();
+        c = nullptr;
     }
     void release_lanes()
     {
@@ -259,7 +271,9 @@ struct Run {
             semz_pool_give(hc, h.d_in, h.in_cap);
             h.d_in = nullptr;
             h.in_cap = 0;
-            HIPCHK(hc, semz_pool_take(hc, span + 64, (void **)&h.d_in, &h.in_cap));
+            hipError_t e = semz_pool_take(hc, span + 64, (void **)&h.d_in, &h.in_cap);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return RC_OOM; }   // (the walk decodes this range on demand)
+            HIPCHK(hc, e);
         }
         HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
         if (r.out_room > (SIZE_MAX >> 2)) return RC_OOM;
@@ -471,22 +485,9 @@ struct Run {
     }
     static uint64_t sat_mul64(uint64_t a, uint64_t b) { uint64_t r; return __builtin_mul_overflow(a, b, &r) ? ~0ull : r; }
     static uint64_t sat4(uint64_t v) { return v > (~0ull >> 2) ? ~0ull : v * 4; }
-    // (the lanes of the primary device take their buffers from one pool, from several threads)
-    static std::mutex &pool_mutex()
-    {
-        static std::mutex m;
-        return m;
-    }
-    static hipError_t pool_take_locked(semz_ctx *pc, size_t bytes, void **p, size_t *cap)
-    {
-        std::lock_guard<std::mutex> g(pool_mutex());
-        return semz_pool_take(pc, bytes, p, cap);
-    }
-    static void pool_give_locked(semz_ctx *pc, void *p, size_t cap)
-    {
-        std::lock_guard<std::mutex> g(pool_mutex());
-        semz_pool_give(pc, p, cap);
-    }
+    // (the lanes of the primary device take their buffers from one pool, from several threads: the pool locks itself)
+    static hipError_t pool_take_locked(semz_ctx *pc, size_t bytes, void **p, size_t *cap) { return semz_pool_take(pc, bytes, p, cap); }
+    static void pool_give_locked(semz_ctx *pc, void *p, size_t cap) { semz_pool_give(pc, p, cap); }
     // one unit with an unknown output size: retried with a larger span while it reports SEMZ_E_OUT_CAP.
     // `limit` is the largest span that can be of use (a declared size, or what the format can expand to from the
     // bytes that are left); a span the device cannot give is SEMZ_E_NO_MEMORY for the stream, not a failed call.
@@ -663,7 +664,43 @@ struct Run {
     }
 };
 
-struct Outcome { int status = SEMZ_OK; uint32_t detail = 0; uint64_t consumed = 0; };
+// What the stream's result says about its end.  `detail` is the first argument of the reference's message.  A
+// message with a second argument finds it in `aux`, unless that argument is a checksum the decoder computed (the
+// "got" of "wanted ..., got ..."), which is in `check` as in a unit's result (little-endian bytes, check_len of them).
+struct Outcome {
+    int status = SEMZ_OK;
+    uint32_t detail = 0;
+    uint64_t consumed = 0;
+    uint32_t aux = 0;
+    uint8_t check[32] = {0};
+    uint32_t check_len = 0;
+    void set_check32(uint32_t v) { for (int i = 0; i < 4; i++) check[i] = (uint8_t)(v >> (8 * i)); check_len = 4; }
+};
+
+// The failure of a unit becomes the failure of the stream.  Second arguments of messages that the kernels do not
+// carry are worked out here from the unit's result and the input: deflate.lisp:330 (the reach the window allowed:
+// bytes produced so far, preset history included, capped by the window), deflate.lisp:384 (the value NLEN should
+// have had), gzip.lisp:77 (the header's real CRC-16), gzip.lisp:112 (the real size).
+void fail_from_unit(Outcome &oc, const semz_result &r, const uint8_t *in, uint64_t in_len, uint64_t unit_start, uint64_t window,
+                    uint64_t prefix_len)
+{
+    oc.status = r.status;
+    oc.detail = r.detail;
+    memcpy(oc.check, r.check, sizeof oc.check);
+    oc.check_len = r.check_len;
+    const uint64_t end = (r.in_end_bit + 7) >> 3;
+    switch (r.status) {
+    case SEMZ_E_DEFLATE_DISTANCE: oc.aux = (uint32_t)std::min<uint64_t>(r.out_len + prefix_len, window ? window : 32768); break;
+    case SEMZ_E_DEFLATE_STORED_LEN:                               // LEN is the two bytes in front of NLEN, which was read last
+        if (end >= 4 && end <= in_len) oc.aux = ((uint32_t)in[end - 4] | (uint32_t)in[end - 3] << 8) ^ 0xFFFFu;
+        break;
+    case SEMZ_E_GZIP_HEADER_CRC:                                  // the stored CRC-16 was read last
+        if (end >= unit_start + 2 && end <= in_len) oc.aux = crc32_host(in + unit_start, end - 2 - unit_start) & 0xFFFFu;
+        break;
+    case SEMZ_E_GZIP_ISIZE: oc.aux = (uint32_t)r.out_len; break;
+    default: break;
+    }
+}
 
 inline uint64_t sat_mul(uint64_t a, uint64_t b) { uint64_t r; return __builtin_mul_overflow(a, b, &r) ? ~0ull : r; }
 inline uint64_t sat_add(uint64_t a, uint64_t b) { uint64_t r; return __builtin_add_overflow(a, b, &r) ? ~0ull : r; }
@@ -827,7 +864,12 @@ int run_deflate_family(Run &R, int fmt, bool all_members, Outcome &oc, semz_stre
             info->nmembers = 0;
         }
         oc.consumed = pos + ((r.in_end_bit - 8 * pos + 7) >> 3);
-        if (r.status != SEMZ_OK) { oc.status = r.status; oc.detail = r.detail; return 0; }
+        if (r.status != SEMZ_OK) {
+            // (zlib enforces the window its header declares, zlib.lisp:36, 53)
+            const uint64_t window = fmt == SEMZ_FMT_ZLIB && pos < R.in_len && (R.in[pos] >> 4) <= 7 ? 256ull << (R.in[pos] >> 4) : 32768;
+            fail_from_unit(oc, r, R.in, R.in_len, pos, window, 0);
+            return 0;
+        }
         R.emit(r.out_off, r.out_len);
         R.member_done(oc.consumed);
         if (info) info->nmembers = member + 1;
@@ -918,7 +960,8 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
                     if (rc) return rc;
                 }
                 if (r.status != SEMZ_OK) {
-                    oc.status = r.status; oc.detail = r.detail; oc.consumed = (r.in_end_bit + 7) >> 3;
+                    fail_from_unit(oc, r, R.in, R.in_len, bit >> 3, 0, 0);
+                    oc.consumed = (r.in_end_bit + 7) >> 3;
                     return 0;
                 }
                 R.emit(r.out_off, r.out_len);
@@ -930,7 +973,11 @@ int run_bzip2(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
                 if (8 * R.in_len - bit < 32) { oc.status = SEMZ_EOF; oc.consumed = R.in_len; return 0; }
                 const uint32_t want = (uint32_t)read_bits_be(R.in, R.in_len, bit, 32);
                 bit += 32;
-                if (want != stream_crc) { oc.status = SEMZ_E_BZ_STREAM_CRC; oc.detail = want; oc.consumed = (bit + 7) >> 3; return 0; }
+                if (want != stream_crc) {
+                    oc.status = SEMZ_E_BZ_STREAM_CRC; oc.detail = want; oc.consumed = (bit + 7) >> 3;
+                    oc.set_check32(stream_crc);
+                    return 0;
+                }
                 break;
             } else {
                 oc.status = SEMZ_E_BZ_BLOCK_MAGIC; oc.consumed = (bit + 48 + 7) >> 3;
@@ -992,7 +1039,11 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
             if (pos >= n) return fail(SEMZ_EOF, 0, n);
             if (in[pos] == 0) { pos++; break; }
             XzBlockHeader h = parse_xz_block_header(in, pos, n);
-            if (h.status != SEMZ_OK) return fail(h.status, h.detail, h.status == SEMZ_EOF ? n : pos + h.header_size + 4);
+            if (h.status != SEMZ_OK) {
+                if (h.status == SEMZ_E_XZ_BLOCK_HDR_CRC) oc.set_check32(h.detail2);
+                else oc.aux = h.detail2;
+                return fail(h.status, h.detail, h.status == SEMZ_EOF ? n : pos + h.header_size + 4);
+            }
             const uint64_t data = pos + h.header_size + 4;
             semz_unit u{};
             u.kind = SEMZ_UNIT_XZ_BLOCK;
@@ -1026,7 +1077,10 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
                     if (rc) return rc;
                 }
             }
-            if (r.status != SEMZ_OK) return fail(r.status, r.detail, (r.in_end_bit + 7) >> 3);
+            if (r.status != SEMZ_OK) {
+                fail_from_unit(oc, r, in, n, data, 0, 0);
+                return fail(r.status, r.detail, (r.in_end_bit + 7) >> 3);
+            }
             R.emit(r.out_off, r.out_len);
             const uint64_t real_csize = ((uint64_t)r.detail << 32) | r.aux;
             seen.emplace_back(h.header_size + 4 + real_csize + xz_check_size(ct), r.out_len);
@@ -1067,13 +1121,19 @@ int run_xz(Run &R, bool all_members, Outcome &oc, semz_stream_info *info)
             if (n - pos < 4) return fail(SEMZ_EOF, 0, n);
             const uint32_t icrc = (uint32_t)in[pos] | ((uint32_t)in[pos + 1] << 8) | ((uint32_t)in[pos + 2] << 16) | ((uint32_t)in[pos + 3] << 24);
             pos += 4;
-            if (icrc != crc32_host(ridx.data(), ridx.size())) return fail(SEMZ_E_XZ_INDEX_CRC, icrc, pos);
+            if (icrc != crc32_host(ridx.data(), ridx.size())) {
+                oc.set_check32(crc32_host(ridx.data(), ridx.size()));
+                return fail(SEMZ_E_XZ_INDEX_CRC, icrc, pos);
+            }
             if (n - pos < 12) return fail(SEMZ_EOF, 0, n);
             const uint8_t *f = in + pos;
             pos += 12;
             const uint32_t fcrc = (uint32_t)f[0] | ((uint32_t)f[1] << 8) | ((uint32_t)f[2] << 16) | ((uint32_t)f[3] << 24);
             const uint32_t bsz = (uint32_t)f[4] | ((uint32_t)f[5] << 8) | ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 24);
-            if (fcrc != crc32_host(f + 4, 6)) return fail(SEMZ_E_XZ_FOOTER_CRC, fcrc, pos);
+            if (fcrc != crc32_host(f + 4, 6)) {
+                oc.set_check32(crc32_host(f + 4, 6));
+                return fail(SEMZ_E_XZ_FOOTER_CRC, fcrc, pos);
+            }
             if (4ull * ((uint64_t)bsz + 1) != 4 + ridx.size()) return fail(SEMZ_E_XZ_BACKWARD_SIZE, 0, pos);
             if (stream_flags != ((uint32_t)f[8] | ((uint32_t)f[9] << 8))) return fail(SEMZ_E_XZ_FOOTER_FLAGS, 0, pos);
             if (f[10] != 0x59 || f[11] != 0x5A) return fail(SEMZ_E_XZ_FOOTER_MAGIC, 0, pos);
@@ -1201,8 +1261,22 @@ struct semz_decoded { Run run; };
 extern "C" void semz_stream_release(semz_decoded *d)
 {
     if (!d) return;
-    (void)hipSetDevice(d->run.c->device);
+    if (semz_ctx *c = d->run.c) {               // (a stream that outlived its context holds host memory only)
+        std::lock_guard<std::mutex> g(c->mu);
+        for (size_t i = 0; i < c->live.size(); i++)
+            if (c->live[i] == d) { c->live.erase(c->live.begin() + i); break; }
+    }
     delete d;
+}
+
+void semz_stream_orphan_all(semz_ctx *c)
+{
+    std::vector<semz_decoded *> live;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        live.swap(c->live);
+    }
+    for (semz_decoded *d : live) d->run.free_device();
 }
 
 // `sink`: the buffer the caller wants the stream in (semz_decode_stream_into), which the batch loop fills directly
@@ -1266,8 +1340,17 @@ static int stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len,
     res->detail = oc.detail;
     res->in_end_bit = 8 * oc.consumed;
     res->out_len = R.emitted;
+    if (oc.status != SEMZ_OK) {                 // the other arguments of the reference's message (see Outcome)
+        res->aux = oc.aux;
+        memcpy(res->check, oc.check, sizeof res->check);
+        res->check_len = oc.check_len;
+    }
     si.total_out = R.emitted;
     if (info) *info = si;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->live.push_back(Rp);
+    }
     *decoded = Rp;
     return 0;
 }
@@ -1290,6 +1373,7 @@ extern "C" int semz_stream_read(semz_decoded *d, uint64_t offset, void *dst, siz
 {
     if (!d) return -1;
     semz_ctx *c = d->run.c;
+    if (!c) return -6;                          // the context was closed: the decoded data went with it
     if (!dst && len) return semz_fail(c, -1, "null pointer");
     HIPCHK(c, hipSetDevice(c->device));
     return d->run.read(offset, (uint8_t *)dst, len);

@@ -258,9 +258,20 @@ void semz_free(void *p);
  * in unit order (bzip2 stream CRC fold bzip2.lisp:42-49,489-494; xz index and
  * footer xz.lisp:166-233; "unit k ends where unit k+1 starts"; trailing data
  * interface.lisp:125-130), first error wins.  *out is malloc'ed (semz_free).
- * res->status is the stream's status; res->out_len the total output;
- * res->in_end_bit/8 the bytes consumed.  all_members == 0 decodes the first
- * member only (interface.lisp:149-186). */
+ * res->status is the stream's status; res->out_len the total output (for a
+ * failed stream: everything the reference delivers before it reaches the bad
+ * data, interface.lisp:95-108 -- the complete members and the good units of the
+ * member that failed); res->in_end_bit/8 the bytes consumed.  A failed stream's
+ * result also carries the other arguments of the reference's message beside
+ * res->detail (its first): res->check / check_len = the checksum the decoder
+ * computed, where the message prints one ("wanted ~8,'0x, got ~8,'0x":
+ * zlib.lisp:75, gzip.lisp:108, bzip2.lisp:493, 520, xz.lisp:209, 220, 404, 452);
+ * res->aux = a second argument of another kind (deflate.lisp:330 the reach the
+ * window allowed, deflate.lisp:384 the required NLEN, gzip.lisp:77 the real
+ * header CRC-16, gzip.lisp:112 the real size, xz.lisp:342 the alignment).  The
+ * stored check of an xz block (xz.lisp:452, first argument) is in the input
+ * itself, the check_len bytes that end at in_end_bit/8.  all_members == 0
+ * decodes the first member only (interface.lisp:149-186). */
 int semz_decode_stream(semz_ctx *ctx, int fmt, const uint8_t *in, size_t in_len,
                        int all_members, uint8_t **out, size_t *out_len,
                        semz_result *res, semz_stream_info *info);

@@ -149,14 +149,142 @@ signals `engine-error' (bind `*enabled*' to nil to use the reference's decoders)
 
 ;;;; Conditions: one status per `die' site of the reference (include/semz_status.h)
 
-(defun signal-status (status detail)
-  "Signals what the reference signals for `status'."
-  (cond ((= status 1) (semz.decompress::%eof))                           ; common.lisp:56-57
-        ((= status 44)                                                   ; zlib.lisp:47-48
-         (error 'semz.decompress:unrecognized-zlib-dictionary :checksum detail))
-        ((>= status 200)                                                 ; engine-level, no counterpart in the reference
-         (error 'engine-error :message (semz-strerror status)))
-        (t (semz.decompress::die "~a" (semz-strerror status)))))         ; common.lisp:53-54
+;;; status -> the reference's own format-control string and where its arguments come from:
+;;;   :detail        semz_result.detail, the first argument of the message
+;;;   :aux           semz_result.aux of a failed stream: a second argument that is not a checksum
+;;;   :check         semz_result.check, the checksum the decoder computed ("got"), as the integer the reference compares
+;;;   :high-octet / :low-octet   the two octets packed into detail (bzip2.lisp:430)
+;;;   :stored-check  the check field of the xz block as stored in the input; :hex-digits = twice its size (xz.lisp:452-454)
+;;; Statuses that are not listed have no message in the reference (SEMZ_E_BZ_ORIGPTR, SEMZ_E_LZMA2_NO_STATE: see
+;;; DESIGN.md) and are reported with the engine's text.
+(defparameter *messages*
+  '((10 "Underfull Huffman tree.")                                                        ; huffman.lisp:183
+    (11 "Overfull Huffman tree.")                                                         ; huffman.lisp:184
+    (20 "Block uses reserved BTYPE.")                                                     ; deflate.lisp:397
+    (21 "Checksum mismatch in uncompressed block (required ~4,'0x, got ~4,'0x)." :aux :detail) ; deflate.lisp:384
+    (22 "Code lengths expand beyond bounds.")                                             ; deflate.lisp:187
+    (23 "Tried to repeat non-existent last code length.")                                 ; deflate.lisp:190
+    (24 "Distance code out of bounds (0-29): ~d" :detail)                                 ; deflate.lisp:298
+    (25 "Unique distance code is out of bounds (0-29) or is not ~
+                        encoded as a zero bit.")                                          ; deflate.lisp:304-305
+    (26 "Length code in literal-only block: ~d" :detail)                                  ; deflate.lisp:324
+    (27 "Reference points back further (~d) than the window allows (~d)." :detail :aux)   ; deflate.lisp:330
+    (28 "Invalid literal/length code: ~d" :detail)                                        ; deflate.lisp:336
+    (40 "Unsupported compression method: ~X" :detail)                                     ; zlib.lisp:31
+    (41 "Invalid compression info (must be 0 - 7): ~X" :detail)                           ; zlib.lisp:33
+    (42 "Invalid flag checksum.")                                                         ; zlib.lisp:35
+    (43 "Cannot use preset dictionaries without a dictionary function.")                  ; zlib.lisp:44
+    (45 "Invalid data checksum (wanted ~8,'0x, got ~8,'0x)." :detail :check)              ; zlib.lisp:75
+    (50 "Incorrect gzip magic bytes.")                                                    ; gzip.lisp:62
+    (51 "Unrecognized compression method: ~x" :detail)                                    ; gzip.lisp:64
+    (52 "Reserved flag bits are non-zero.")                                               ; gzip.lisp:66
+    (53 "Inconsistent lengths for gzip extra fields.")                                    ; gzip.lisp:25
+    (54 "Header checksum mismatch (required ~4,'0x, got ~4,'0x)." :detail :aux)           ; gzip.lisp:77
+    (55 "Invalid data checksum (wanted ~8,'0x, got ~8,'0x)." :detail :check)              ; gzip.lisp:108
+    (56 "Invalid data length check (wanted ~d, got ~d)." :detail :aux)                    ; gzip.lisp:112
+    (60 "Incorrect bzip2 magic bytes: ~2,'0x ~2,'0x" :high-octet :low-octet)              ; bzip2.lisp:430
+    (61 "Unrecognized bzip version: ~2,'0x" :detail)                                      ; bzip2.lisp:435
+    (62 "Invalid bzip2 compression level: ~2,'0x" :detail)                                ; bzip2.lisp:437
+    (63 "Unrecognized magic bytes on block boundary.")                                    ; bzip2.lisp:503
+    (64 "Block declares no used symbols.")                                                ; bzip2.lisp:359
+    (65 "Illegal tree count: ~d" :detail)                                                 ; bzip2.lisp:381
+    (66 "Block defines no selectors.")                                                    ; bzip2.lisp:384
+    (67 "Invalid selector: ~d" :detail)                                                   ; bzip2.lisp:307
+    (68 "Code length goes out of bounds.")                                                ; bzip2.lisp:337
+    (69 "Ran out of selectors before end of block.")                                      ; bzip2.lisp:250
+    (70 "A/B run cannot possibly stay in bounds.")                                        ; bzip2.lisp:262
+    (71 "A/B run expands beyond block size.")                                             ; bzip2.lisp:272
+    (72 "Too many codes/expansions.")                                                     ; bzip2.lisp:283
+    (73 "Invalid block CRC (expected ~8,'0x, got ~8,'0x)." :detail :check)                ; bzip2.lisp:520
+    (74 "Incorrect stream CRC (expected ~8,'0x, got ~8,'0x)" :detail :check)              ; bzip2.lisp:493
+    (80 "LZMA data doesn't begin with a zero octet.")                                     ; lzma.lisp:58
+    (81 "Code starts out of range.")                                                      ; lzma.lisp:61
+    (82 "Code goes out of range.")                                                        ; lzma.lisp:73, 188
+    (83 "Match extends beyond dictionary size.")                                          ; lzma.lisp:605
+    (84 "Match extends beyond available data.")                                           ; lzma.lisp:607
+    (85 "Match extends beyond declared decompressed size.")                               ; lzma.lisp:609
+    (86 "Decompressed data goes beyond declared size.")                                   ; lzma.lisp:718
+    (87 "Didn't find mandatory EOF marker in LZMA data.")                                 ; lzma.lisp:643
+    (88 "Illegal EOF marker in LZMA data.")                                               ; lzma.lisp:646, 730
+    (89 "LZMA data continues beyond declared size.")                                      ; lzma.lisp:647
+    (90 "Neither range decoder nor marker denote an end.")                                ; lzma.lisp:659
+    (91 "Range decoder finishes in invalid state.")                                       ; lzma.lisp:774
+    (92 "Decompressed data ends before declared size.")                                   ; lzma.lisp:894
+    (93 "Property `pb' is out of bounds (0-4): ~d" :detail)                               ; lzma.lisp:842
+    (100 "Property lc+lp out of bounds (0-4): ~d" :detail)                                ; lzma2.lisp:36
+    (101 "Unrecognized LZMA2 dictionary size byte.")                                      ; lzma2.lisp:42
+    (102 "Didn't get required dictionary reset.")                                         ; lzma2.lisp:98, 160
+    (103 "Didn't get required property reset.")                                           ; lzma2.lisp:100
+    (104 "Embedded LZMA data goes beyond LZMA2 block size.")                              ; lzma2.lisp:116
+    (105 "Illegal LZMA2 control byte: ~2,'0x" :detail)                                    ; lzma2.lisp:149
+    (106 "Embedded LZMA data is shorter than declared.")                                  ; lzma2.lisp:201
+    (120 "Invalid XZ magic bytes.")                                                       ; xz.lisp:91
+    (121 "Reserved header byte isn't zero.")                                              ; xz.lisp:93
+    (122 "Incorrect header checksum.")                                                    ; xz.lisp:100
+    (123 "Reserved header flag bits aren't zero.")                                        ; xz.lisp:102
+    (124 "Unsupported checksum type: ~X" :detail)                                         ; xz.lisp:104
+    (125 "Trailing garbage data after XZ stream.")                                        ; xz.lisp:133
+    (126 "XZ padding doesn't come in multiples of 4 bytes.")                              ; xz.lisp:134
+    (127 "Overlong multibyte integer encoding.")                                          ; xz.lisp:151
+    (128 "Overlong multibyte integer.")                                                   ; xz.lisp:154
+    (129 "Index padding contains non-zero bytes.")                                        ; xz.lisp:190
+    (130 "Index disagrees with the observed number of blocks.")                           ; xz.lisp:196
+    (131 "Index disagrees with the observed block sizes.")                                ; xz.lisp:203
+    (132 "Incorrect index CRC (expected ~8,'0x, got ~8,'0x)." :detail :check)             ; xz.lisp:209
+    (133 "Incorrect footer CRC (expected ~8,'0x, got ~8,'0x)." :detail :check)            ; xz.lisp:220
+    (134 "Incorrect backwards size field.")                                               ; xz.lisp:225
+    (135 "Inconsistent stream flags between header and footer.")                          ; xz.lisp:228
+    (136 "Invalid footer magic bytes.")                                                   ; xz.lisp:230
+    (137 "Reserved block header bits aren't zero.")                                       ; xz.lisp:267
+    (138 "Block header is truncated.")                                                    ; xz.lisp:288
+    (139 "Block header padding contains non-zero bytes.")                                 ; xz.lisp:291
+    (140 "Embedded compressed data goes beyond declared XZ block size.")                  ; xz.lisp:309
+    (141 "The Delta filter must not come last.")                                          ; xz.lisp:316
+    (142 "Invalid property length for Delta filter: ~d" :detail)                          ; xz.lisp:318
+    (143 "BCJ filters must not come last.")                                               ; xz.lisp:325
+    (144 "Invalid property length for BCJ filter: ~d" :detail)                            ; xz.lisp:330
+    (145 "Offset ~8,0x is not aligned to ~d" :detail :aux)                                ; xz.lisp:342
+    (146 "The LZMA2 filter must always come last.")                                       ; xz.lisp:348
+    (147 "Invalid property length for LZMA2 filter: ~d" :detail)                          ; xz.lisp:350
+    (148 "Reserved LZMA property bits aren't zero.")                                      ; xz.lisp:352
+    (149 "Unrecognized filter type: ~2,'0x" :detail)                                      ; xz.lisp:377
+    (150 "Invalid block header CRC (expected ~8,'0x, got ~8,'0x)." :detail :check)        ; xz.lisp:404
+    (151 "Total decompressed size exceeds 2^63 - 1 bytes.")                               ; xz.lisp:421
+    (152 "XZ block is smaller than its declared size.")                                   ; xz.lisp:430
+    (153 "Decompressed size doesn't match declared decompressed size.")                   ; xz.lisp:435
+    (154 "Block padding doesn't consist of null bytes.")                                  ; xz.lisp:442
+    (155 "Incorrect block checksum (expected ~v,'0x, got ~v,'0x)."
+     :hex-digits :stored-check :hex-digits :check)                                        ; xz.lisp:452-454
+    (156 "XZ stream is longer than 2^63 - 1 bytes.")                                      ; xz.lisp:87
+    (170 "Trailing data detected.")))                                                     ; interface.lisp:130
+
+(defstruct (failure (:constructor make-failure (status detail aux check check-size stored-check)))
+  "Where a decoded stream stopped: the status and the arguments of the reference's message for it."
+  status detail aux check check-size stored-check)
+
+(defun signal-failure (failure)
+  "Signals what the reference signals for the status, with the reference's message and arguments."
+  (let ((status (failure-status failure))
+        (detail (failure-detail failure)))
+    (cond ((= status 1) (semz.decompress::%eof))                         ; common.lisp:56-57
+          ((= status 44)                                                 ; zlib.lisp:47-48
+           (error 'semz.decompress:unrecognized-zlib-dictionary :checksum detail))
+          ((>= status 200)                                               ; engine-level, no counterpart in the reference
+           (error 'engine-error :message (semz-strerror status)))
+          (t
+           (let ((entry (assoc status *messages*)))
+             (if (null entry)
+                 (semz.decompress::die "~a" (semz-strerror status))      ; common.lisp:53-54
+                 (apply #'semz.decompress::die (second entry)
+                        (loop :for source :in (cddr entry)
+                              :collect (ecase source
+                                         (:detail detail)
+                                         (:aux (failure-aux failure))
+                                         (:check (failure-check failure))
+                                         (:high-octet (ldb (byte 8 8) detail))
+                                         (:low-octet (ldb (byte 8 0) detail))
+                                         (:hex-digits (* 2 (failure-check-size failure)))
+                                         (:stored-check (failure-stored-check failure)))))))))))
 
 (defparameter *header-statuses*
   '(40 41 42 43 44          ; zlib.lisp:30-48
@@ -206,7 +334,9 @@ signals `engine-error' (bind `*enabled*' to nil to use the reference's decoders)
    (%members :initarg :members :reader gbs-members)     ; simple-vector of (in-end . out-end), one per decoded member
    (%index :initform 0 :accessor gbs-index)             ; the member being handed out
    (%offset :initform 0 :accessor gbs-offset)           ; octets of output handed out so far
-   (%pending :initarg :pending :accessor gbs-pending)   ; (status . detail) of the member after the last good one, or nil
+   (%out-len :initarg :out-len :reader gbs-out-len)     ; octets the whole decode produced: the members, and what the
+                                                        ; member that failed had delivered before its bad data
+   (%pending :initarg :pending :accessor gbs-pending)   ; `failure' of the member after the last good one, or nil
    (%chunk :initform semz.decompress::+dummy-buffer+ :accessor gbs-chunk))
   (:documentation "All members of one input, decoded by the engine and waiting in device memory."))
 
@@ -223,6 +353,15 @@ and callers that go on reading after a member look at it."
         (min (semz.decompress::buffer-stream-end (gbs-source state))
              (+ (gbs-base state) input-octets))))
 
+(defun fetch-chunk (state n)
+  "Octets [offset, offset + n) of the decoded stream into the state's chunk vector, straight from the device."
+  (when (< (length (gbs-chunk state)) n)
+    (setf (gbs-chunk state)
+          (make-array (min *chunk-size* (max n 65536)) :element-type 'semz.decompress::octet)))
+  (when (plusp n)
+    (cffi:with-pointer-to-vector-data (dst (gbs-chunk state))            ; pins the vector for the copy
+      (check-rc (semz-stream-read (gbs-handle state) (gbs-offset state) dst n) "semz_stream_read"))))
+
 (defmethod semz.decompress::next-decompressed-chunk ((state gpu-batch-state))
   (let ((members (gbs-members state))
         (k (gbs-index state)))
@@ -230,12 +369,7 @@ and callers that go on reading after a member look at it."
       ((< k (length members))
        (destructuring-bind (in-end . out-end) (svref members k)
          (let ((n (min *chunk-size* (- out-end (gbs-offset state)))))
-           (when (< (length (gbs-chunk state)) n)
-             (setf (gbs-chunk state)
-                   (make-array (min *chunk-size* (max n 65536)) :element-type 'semz.decompress::octet)))
-           (when (plusp n)
-             (cffi:with-pointer-to-vector-data (dst (gbs-chunk state))      ; pins the vector for the copy
-               (check-rc (semz-stream-read (gbs-handle state) (gbs-offset state) dst n) "semz_stream_read")))
+           (fetch-chunk state n)
            (incf (gbs-offset state) n)
            (let ((finalp (= (gbs-offset state) out-end)))
              (when finalp
@@ -243,10 +377,16 @@ and callers that go on reading after a member look at it."
                (when (and (= (1+ k) (length members)) (null (gbs-pending state)))
                  (release-decoded state)))
              (values (gbs-chunk state) 0 n finalp)))))
+      ;; The member that failed: the reference hands out every chunk it decodes before it reaches the bad data
+      ;; (interface.lisp:95-108), and the engine has those octets behind the last complete member.
+      ((and (gbs-pending state) (< (gbs-offset state) (gbs-out-len state)))
+       (let ((n (min *chunk-size* (- (gbs-out-len state) (gbs-offset state)))))
+         (fetch-chunk state n)
+         (incf (gbs-offset state) n)
+         (values (gbs-chunk state) 0 n nil)))
       ((gbs-pending state)
        (release-decoded state)
-       (destructuring-bind (status . detail) (gbs-pending state)
-         (signal-status status detail)))
+       (signal-failure (gbs-pending state)))
       (t (values semz.decompress::+dummy-buffer+ 0 0 t)))))
 
 (defmethod semz.decompress::make-reset-state ((state gpu-batch-state))
@@ -351,18 +491,37 @@ stream (io.lisp:42-57) start out empty, counted sources are views of another sou
               (setf (svref table i)
                     (cons (cffi:foreign-slot-value m '(:struct semz-member) 'in-end)
                           (cffi:foreign-slot-value m '(:struct semz-member) 'out-end)))))
-          ;; a header the reference rejects is rejected here, where the reference rejects it
-          (when (and (zerop n) (member status *header-statuses*))
-            (semz-stream-release handle)
-            (signal-status status detail))
-          (let ((state (make-instance 'gpu-batch-state
-                                      :format format :source byte-source :base base :consumed consumed
-                                      :handle handle :members table
-                                      :pending (if (zerop status) nil (cons status detail)))))
-            ;; a caller that stops reading early (first member only, an abandoned stream) never reaches the
-            ;; release in `next-decompressed-chunk': the collector returns the device memory then
-            #+sbcl (sb-ext:finalize state (lambda () (semz-stream-release handle)) :dont-save t)
-            (values state (header-plist format info buffer base))))))))
+          (let ((failure
+                  (if (zerop status)
+                      nil
+                      (let* ((check-len (cffi:foreign-slot-value res '(:struct semz-result) 'check-len))
+                             (check-ptr (cffi:foreign-slot-pointer res '(:struct semz-result) 'check))
+                             ;; the xz block's check field ends where the decode stopped (xz.lisp:444-450)
+                             (stored-end (+ base consumed)))
+                        (make-failure status detail
+                                      (cffi:foreign-slot-value res '(:struct semz-result) 'aux)
+                                      (loop :for i :below check-len   ; little-endian, as the reference compares it
+                                            :sum (ash (cffi:mem-aref check-ptr :uint8 i) (* 8 i)))
+                                      check-len
+                                      (if (and (= status 155) (<= (+ base check-len) stored-end end))
+                                          (loop :for i :below check-len
+                                                :sum (ash (aref buffer (+ (- stored-end check-len) i)) (* 8 i)))
+                                          0))))))
+            ;; a header the reference rejects is rejected here, where the reference rejects it
+            (when (and failure (zerop n) (member status *header-statuses*))
+              (semz-stream-release handle)
+              (signal-failure failure))
+            (let ((state (make-instance 'gpu-batch-state
+                                        :format format :source byte-source :base base :consumed consumed
+                                        :handle handle :members table
+                                        :out-len (cffi:foreign-slot-value res '(:struct semz-result) 'out-len)
+                                        :pending failure)))
+              ;; a caller that stops reading early (first member only, an abandoned stream) never reaches the
+              ;; release in `next-decompressed-chunk': the collector returns the device memory then
+              ;; (after `close-engine' too: semz_close cuts the decoded streams of its context loose, and releasing one
+              ;; of those frees host memory only)
+              #+sbcl (sb-ext:finalize state (lambda () (semz-stream-release handle)) :dont-save t)
+              (values state (header-plist format info buffer base)))))))))
 
 (macrolet ((define-dispatch (&rest formats)
              `(progn

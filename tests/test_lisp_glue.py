@@ -185,3 +185,67 @@ def test_constants_match_headers():
     api = open(os.path.join(ROOT, "decompress_amd", "csrc", "semz_api.hip")).read()
     for opt in set(re.findall(r'\(cons "([a-z-]+)"', code)):
         assert f'"{opt}"' in api, opt
+
+
+def glue_messages():
+    """*messages* of lisp/gpu.lisp: {status: (control string, source keywords...)}"""
+    text = open(GLUE).read()
+    body = text[text.index("(defparameter *messages*"):text.index("(defstruct (failure")]
+    out = {}
+    for m in re.finditer(r'\((\d+) "((?:[^"\\]|\\.)*)"((?:\s+:[a-z-]+)*)\)', body, flags=re.S):
+        out[int(m.group(1))] = (m.group(2),) + tuple(k[1:] for k in m.group(3).split())
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+def test_message_control_strings_are_the_references():
+    """Every format-control string the glue signals with is byte-identical to one of the reference's `die` calls."""
+    ref = set()
+    for path in glob.glob(os.path.join(REF, "*.lisp")):
+        ref.update(re.findall(r'\(die\s+"((?:[^"\\]|\\.)*)"', open(path).read(), flags=re.S))
+    assert len(ref) > 90
+    msgs = glue_messages()
+    assert len(msgs) > 90
+    for status, entry in msgs.items():
+        assert entry[0] in ref, (status, entry[0])
+    # and the other way round: every `die` of the hot path has a status that signals it (sha256.lisp:142 is unreachable
+    # per unit, SURVEY.md section 8a a26)
+    used = {e[0] for e in msgs.values()}
+    assert ref - used == {"Input data is too long for SHA-256."}, ref - used
+    # the number of arguments fits the directives that take one
+    for status, entry in msgs.items():
+        directives = re.findall(r"~(?:[0-9v]*(?:,'?.)?)?([dxXa])", entry[0])
+        vs = len(re.findall(r"~v", entry[0]))
+        assert len(entry) - 1 == len(directives) + vs, (status, entry)
+
+
+def test_python_mirror_has_the_same_messages():
+    """decompress_amd/api.py (the executed mirror) and lisp/gpu.lisp signal with the same table; every status of
+    include/semz_status.h that stands for a `die` site is in it."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from decompress_amd import api
+    msgs = glue_messages()
+    assert api.MESSAGES == msgs
+    status = open(os.path.join(ROOT, "include", "semz_status.h")).read()
+    values = {int(v) for v in re.findall(r"SEMZ_\w+ = (\d+)", status)}
+    no_message = {0, 1, 44, 75, 107}          # ok, eof, the dictionary condition, two divergences without a reference message
+    assert {v for v in values if v < 200} - no_message == set(msgs)
+    listed = re.search(r"\(defparameter \*header-statuses\*\s+'\(([^)]*)\)", strip_lisp(open(GLUE).read())).group(1)
+    assert {int(v) for v in listed.split()} == api._HEADER_STATUSES
+    assert re.search(r"\(defvar \*chunk-size\* \(\* 4 1024 1024\)", open(GLUE).read()) and api.CHUNK_SIZE == 4 << 20
+
+
+def test_lisp_format_subset():
+    import sys
+    sys.path.insert(0, ROOT)
+    from decompress_amd.api import lisp_format, Failure
+    assert lisp_format("Invalid selector: ~d", [7]) == "Invalid selector: 7"
+    assert lisp_format("(wanted ~8,'0x, got ~8,'0x).", [0x1234, 0xABCDEF01]) == "(wanted 00001234, got ABCDEF01)."
+    assert lisp_format("method: ~x", [255]) == "method: FF" and lisp_format("~2,'0x ~2,'0x", [0x42, 5]) == "42 05"
+    assert lisp_format("(expected ~v,'0x, got ~v,'0x).", [8, 1, 8, 2]) == "(expected 00000001, got 00000002)."
+    assert lisp_format("is not ~\n        encoded", []) == "is not encoded"
+    assert lisp_format("~a", ["text"]) == "text"
+    f = Failure(60, 0x4259)
+    assert f.message() == "Incorrect bzip2 magic bytes: 42 59"
+    assert Failure(155, 1, 0, 0xAB, 4, 0xCD).message() == "Incorrect block checksum (expected 000000CD, got 000000AB)."
