@@ -151,13 +151,14 @@ def _split(fmt_id, data):
     return arr, info
 
 
-def make_blobs(fmt, nunits, unit_bytes, seed, workers, check="crc64", cache=None):
-    """The distinct compressed inputs of a workload.  `cache` (a directory) keeps them between runs on one box: the
+def make_blobs(fmt, nunits, unit_bytes, seed, workers, check="crc64", cache=None, first=0):
+    """The distinct compressed inputs [first, first + nunits) of a workload (unit i is made from seed + i, so the
+    ranks of a multi-process run hold contiguous ranges of one corpus).  `cache` (a directory) keeps them between runs on one box: the
     profiling scripts fill it in a run of their own, so that no run under rocprofv3 starts a child process
     (the xz tool, pool workers) after the profiler has initialised the GPU."""
     path = None
     if cache:
-        path = os.path.join(cache, f"{fmt}_{nunits}x{unit_bytes}_{seed:x}_{check if fmt == 'xz' else 'x'}.npz")
+        path = os.path.join(cache, f"{fmt}_{first}+{nunits}x{unit_bytes}_{seed:x}_{check if fmt == 'xz' else 'x'}.npz")
         if os.path.exists(path):
             z = np.load(path)
             ends = np.cumsum(z["lengths"])
@@ -165,10 +166,10 @@ def make_blobs(fmt, nunits, unit_bytes, seed, workers, check="crc64", cache=None
             return [raw[e - l:e] for e, l in zip(ends.tolist(), z["lengths"].tolist())]
     if fmt in ("gzip", "zlib"):
         step = max(1, nunits // (workers * 4))
-        jobs = [(lo, min(nunits, lo + step), unit_bytes, seed) for lo in range(0, nunits, step)]
+        jobs = [(lo, min(first + nunits, lo + step), unit_bytes, seed) for lo in range(first, first + nunits, step)]
         parts = _pool_map(_make_gzip_members if fmt == "gzip" else _make_zlib_records, jobs, workers)
     else:
-        jobs = [(i, i + 1, unit_bytes, seed) + ((check,) if fmt == "xz" else ()) for i in range(nunits)]
+        jobs = [(i, i + 1, unit_bytes, seed) + ((check,) if fmt == "xz" else ()) for i in range(first, first + nunits)]
         parts = _pool_map(_make_bzip2_streams if fmt == "bzip2" else _make_xz_streams, jobs, workers)
     blobs = [b for p in parts for b in p]
     if path:
@@ -177,11 +178,11 @@ def make_blobs(fmt, nunits, unit_bytes, seed, workers, check="crc64", cache=None
     return blobs
 
 
-def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64", replicate=1, cache=None, blobs=None):
+def build_workload(fmt, nunits, unit_bytes, seed, workers, check="crc64", replicate=1, cache=None, blobs=None, first=0):
     """Returns dict(data, uarr, nunits, total_out, total_in, kind, blobs, out_cap)."""
     from decompress_amd import _lib
     if blobs is None:
-        blobs = make_blobs(fmt, nunits, unit_bytes, seed, workers, check, cache)
+        blobs = make_blobs(fmt, nunits, unit_bytes, seed, workers, check, cache, first)
     if fmt in ("gzip", "zlib"):
         kind = _lib.UNIT_GZIP if fmt == "gzip" else _lib.UNIT_ZLIB
         data = b"".join(blobs)
@@ -543,12 +544,18 @@ def main():
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = a.workers or max(1, min(16, ncpu // max(1, world)))
     cache = a.corpus_cache or None
-    seed = 0x5EED0001 + rank * 1000003
+    seed = 0x5EED0001
+    # Across processes the units shard by rank (decompress_amd/shard.py): rank r owns one contiguous range of the
+    # job's units -- world x nunits of them, every unit the same size, so the ranges are equal (weak scaling) -- and
+    # generates just those.
+    from decompress_amd import shard
+    first, last = shard.partition([unit_bytes] * (nunits * world), world)[rank]
+    assert last - first == nunits
 
     # ---- host phase: corpora and CPU baselines, all before the GPU is initialised (pool workers are forked)
     t_gen = time.perf_counter()
     log(f"corpus: {workload}")
-    W = build_workload(a.format, nunits, unit_bytes, seed, workers, a.check, rep, cache)
+    W = build_workload(a.format, nunits, unit_bytes, seed, workers, a.check, rep, cache, first=first)
     t_gen = time.perf_counter() - t_gen
     extras, blob_cache, errors = {}, {}, {}
     for name in extra:
@@ -592,7 +599,13 @@ def main():
 
     # ---- GPU phase
     log("gpu: open, upload")
-    eng = _lib.Engine(local)
+    # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal of the multi-process path on one GPU) the
+    # ranks share what is there
+    ngpu = 1
+    if world > 1:
+        import torch
+        ngpu = max(1, torch.cuda.device_count())
+    eng = _lib.Engine(local % ngpu)
     for kv in a.opt:
         name, value = kv.split("=")
         eng.set_option(name, int(value))
@@ -623,6 +636,13 @@ def main():
         verified = dw.verify(a.format, unit_bytes, who=f"rank {rank}: ")
     except RuntimeError as e:
         raise SystemExit(str(e))
+    if dist is not None:
+        # the host-side gather of the path: per-unit (status, size) in unit order over all ranks, first error wins
+        res = dw.results()
+        flat, first_bad = shard.gather_outcomes(list(zip(res["status"].tolist(), res["out_len"].tolist())), dist)
+        if first_bad is not None or sum(n for _, n in flat) != world * W["total_out"]:
+            raise SystemExit(f"rank {rank}: gathered outcomes: first failing unit {first_bad}, {sum(n for _, n in flat)} bytes")
+        verified += f"; {len(flat)} units gathered over {world} ranks, none failed"
     dw.free()
 
     line = None
@@ -677,7 +697,7 @@ def main():
         if rank == 0:
             try:
                 log(f"gpu: one corpus on {world} GPUs through semz_open_multi")
-                eng_m = _lib.Engine(list(range(world)))
+                eng_m = _lib.Engine([d % ngpu for d in range(world)])
                 try:
                     one = end_to_end(eng, a.format, W, windowed=False)
                     multi = end_to_end(eng_m, a.format, W, windowed=False)

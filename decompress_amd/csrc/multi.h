@@ -1,8 +1,8 @@
 // multi.h -- one input, several GPUs: the partition of a batch of units and the merge of the per-device results.
 //
 // The path shards by unit and has no exchange step: the units of one host-side split are
-// cut into contiguous ranges of about equal compressed size, every range is decoded on a device of its own from
-// the bytes of that range only, and the results come back into the frame of the whole batch, where the host's
+// cut into contiguous ranges of about equal work (output bytes where they are known, compressed bytes otherwise),
+// every range is decoded on a device of its own -- the primary device included -- from the bytes of that range only, and the results come back into the frame of the whole batch, where the host's
 // cross-unit walk (stream CRC fold bzip2.lisp:42-49, xz index xz.lisp:186-203, first error wins
 // interface.lisp:91-133) reads them as if one device had produced them.  These functions are the pure part of
 // that (no HIP): stream.cpp calls them, tests/cpp/test_multi.cpp checks them with made-up per-device results.
@@ -29,9 +29,12 @@ struct MultiRange {
     uint64_t out_lo, out_room;    // fixed: the span of the batch's output the range covers; auto: room asked for
 };
 
-// Contiguous ranges of units, balanced by the compressed bytes between unit starts (units are in input order).
-// `margin` bytes behind the last unit's span are part of a range's input (decoders stage their input in pieces and
-// bzip2 blocks end inside a byte).  Fewer ranges than `parts` come back when there are not enough units.
+// Contiguous ranges of units (units are in input order), balanced by what a device's time goes with: the output
+// bytes where every unit's size is known before it is decoded (fixed spans: gzip ISIZE gzip.lisp:109, the xz index
+// xz.lisp:186-187, caller-supplied record sizes), the compressed bytes between unit starts otherwise (bzip2
+// blocks: SEMZ_OUT_AUTO) -- SURVEY.md section 8e.  `margin` bytes behind the last unit's span are part of a
+// range's input (decoders stage their input in pieces and bzip2 blocks end inside a byte).  Fewer ranges than
+// `parts` come back when there are not enough units.
 inline std::vector<MultiRange> partition_units(const semz_unit *u, size_t n, size_t in_len, unsigned parts, uint64_t margin,
                                                uint64_t auto_room)
 {
@@ -40,14 +43,29 @@ inline std::vector<MultiRange> partition_units(const semz_unit *u, size_t n, siz
     if (parts > n) parts = (unsigned)n;
     const uint64_t lo = u[0].in_off;
     const uint64_t span = in_len > lo ? in_len - lo : 0;
+    // weight of unit i and the running sum in front of it
+    bool by_output = true;
+    for (size_t i = 0; i < n && by_output; i++) by_output = u[i].out_off != SEMZ_OUT_AUTO;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n && by_output; i++) {
+        if (__builtin_add_overflow(total, u[i].out_cap, &total)) by_output = false;      // (sizes are claims of the data)
+    }
+    if (by_output && !total) by_output = false;
+    if (!by_output) total = span;
+    uint64_t before = 0;                                            // weight of the units in front of `end`
     size_t at = 0;
     for (unsigned p = 0; p < parts && at < n; p++) {
-        // the range ends where the input offset passes its share of the bytes
-        const uint64_t goal = lo + (span / parts) * (p + 1);
+        // the range ends where the running weight passes its share
+        const uint64_t goal = (uint64_t)((unsigned __int128)total * (p + 1) / parts);
+        auto weight_before = [&](size_t i) { return by_output ? before : u[i].in_off - lo; };
         size_t end = at + 1;
+        if (by_output) before += u[at].out_cap;
         if (p + 1 == parts) end = n;
         else
-            while (end < n && n - end > parts - 1 - p && u[end].in_off < goal) end++;
+            while (end < n && n - end > parts - 1 - p && weight_before(end) < goal) {
+                if (by_output) before += u[end].out_cap;
+                end++;
+            }
         MultiRange r{};
         r.first = at;
         r.count = end - at;

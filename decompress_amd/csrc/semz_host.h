@@ -50,6 +50,7 @@ struct semz_ctx {
     // device has free when the call starts.
     uint64_t batch_budget = 0;
     uint64_t last_windows = 0;          // windows the last stream call decoded (semz_get_option "windows")
+    uint64_t last_uploaded = 0;         // bytes of input the last stream call sent to devices, all of them ("uploaded-bytes")
     uint64_t last_moved = 0;            // pieces of such windows the last read found out of place in the caller's buffer ("moved")
     // further streams for downloads of large results in parallel slices (created on first use)
     std::vector<hipStream_t> copy_streams;

@@ -64,6 +64,12 @@ struct Run {
         size_t unit_cap = 0;
     };
     std::vector<Helper> helpers;
+    // The primary device's own range of a batch that is spread over several devices: it is decoded from the bytes
+    // of that range only, like the helpers' ranges (the whole input goes up only when the walk has to decode
+    // something by itself, see ensure_input).
+    uint8_t *d_part = nullptr;
+    size_t d_part_cap = 0;
+    std::atomic<uint64_t> uploaded{0};         // bytes of input this call has sent to devices, all of them (option "uploaded-bytes")
     // The batch loop (interface.lisp:91-133, common.lisp:255-257: bounded memory, nothing
     // delivered is lost before an error).  A predicted batch that does not fit `budget` bytes of device memory is
     // decoded window by window (multi.h: window_units): every window uploads its own bytes of the input, decodes
@@ -102,11 +108,12 @@ struct Run {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         semz_pool_give(c, d_in, d_in_cap);
+        semz_pool_give(c, d_part, d_part_cap);
         semz_pool_give(c, d_out, out_cap);
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
-        d_in = d_out = nullptr; d_units = nullptr; d_res = nullptr;
-        d_in_cap = out_cap = unit_cap = 0;
+        d_in = d_out = d_part = nullptr; d_units = nullptr; d_res = nullptr;
+        d_in_cap = out_cap = unit_cap = d_part_cap = 0;
         for (auto &h : helpers) {
             (void)hipSetDevice(h.c->device);
             (void)hipStreamSynchronize(h.c->stream);
@@ -155,8 +162,9 @@ struct Run {
             helpers.push_back(h);
         }
         // an input that takes a good part of the budget by itself goes up window by window, or, if the format has
-        // no units to predict, when the first decode asks for it
-        if (in_len > budget / 4) return 0;
+        // no units to predict, when the first decode asks for it; with several devices every device gets the bytes
+        // of its own range, and the whole input goes to the primary device only if the walk needs it there
+        if (in_len > budget / 4 || (!helpers.empty() && in_len >= (1u << 20))) return 0;
         return ensure_input();
     }
     int ensure_input()
@@ -166,6 +174,7 @@ struct Run {
         if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); d_in = nullptr; return RC_OOM; }
         HIPCHK(c, e);
         HIPCHK(c, hipMemcpyAsync(d_in, in, in_len, hipMemcpyHostToDevice, c->stream));
+        uploaded += in_len;
         return 0;
     }
     // Sizes that come out of the data (declared sizes, index records, ISIZE fields) are untrusted: a request the
@@ -217,9 +226,14 @@ struct Run {
         std::vector<std::thread> th;
         for (size_t p = 1; p < ranges.size(); p++)
             th.emplace_back([&, p] { rcs[p] = decode_on_helper(helpers[p - 1], (unsigned)p, units.data(), ranges[p], arena_base, res.data()); });
-        rcs[0] = decode_on_primary(units.data(), ranges[0].count, res.data(), arena_base, arena_room);
+        rcs[0] = decode_range_on_primary(units.data(), ranges[0], res.data(), arena_base, arena_room);
         for (auto &t : th) t.join();
         HIPCHK(c, hipSetDevice(c->device));
+        if (getenv("SEMZ_TRACE"))
+            for (size_t p = 0; p < ranges.size(); p++)
+                fprintf(stderr, "multi: device %d takes units [%zu, %zu), uploads %llu bytes of %zu, output room %llu\n",
+                        p ? helpers[p - 1].c->device : c->device, ranges[p].first, ranges[p].first + ranges[p].count,
+                        (unsigned long long)(ranges[p].in_hi - ranges[p].in_lo), in_len, (unsigned long long)ranges[p].out_room);
         for (size_t p = 0; p < ranges.size(); p++) {
             if (rcs[p] == RC_OOM) {                 // a helper without the memory: its range is decoded by the walk, on demand
                 for (size_t i = 0; i < ranges[p].count; i++) distrust[ranges[p].first + i] = 1;
@@ -260,6 +274,48 @@ struct Run {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return 0;
     }
+    // The primary device's range of a batch that several devices share: the bytes of the range go up (not the whole
+    // input), the units read them at local offsets and write the arena at the offsets the batch gave them.  A unit
+    // that fails on a span the range cut short is marked for the walk (which decodes it where the whole input is).
+    int decode_range_on_primary(const semz_unit *units, const MultiRange &r, semz_result *res, uint64_t arena_base, uint64_t arena_room)
+    {
+        if (d_in) return decode_on_primary(units, r.count, res, arena_base, arena_room);      // (the whole input is up already)
+        const size_t span = (size_t)(r.in_hi - r.in_lo), n = r.count;
+        if (span + 64 > d_part_cap) {
+            semz_pool_give(c, d_part, d_part_cap);
+            d_part = nullptr;
+            d_part_cap = 0;
+            hipError_t e = semz_pool_take(c, span + 64, (void **)&d_part, &d_part_cap);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); d_part = nullptr; return RC_OOM; }
+            HIPCHK(c, e);
+        }
+        HIPCHK(c, hipMemcpyAsync(d_part, in + r.in_lo, span, hipMemcpyHostToDevice, c->stream));
+        uploaded += span;
+        std::vector<semz_unit> local;
+        std::vector<uint8_t> clamped;
+        localise_units(units, r, local, clamped);
+        for (auto &x : local)
+            if (x.out_off != SEMZ_OUT_AUTO) x.out_off += r.out_lo;         // (output offsets stay those of the batch)
+        if (n > unit_cap) {
+            if (d_units) HIPCHK(c, hipFree(d_units));
+            if (d_res) HIPCHK(c, hipFree(d_res));
+            d_units = nullptr; d_res = nullptr;
+            unit_cap = n + n / 2 + 16;
+            HIPCHK(c, hipMalloc((void **)&d_units, unit_cap * sizeof(semz_unit)));
+            HIPCHK(c, hipMalloc((void **)&d_res, unit_cap * sizeof(semz_result)));
+        }
+        HIPCHK(c, hipMemcpyAsync(d_units, local.data(), n * sizeof(semz_unit), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_res, 0xFF, n * sizeof(semz_result), c->stream));
+        int rc = semz_decode_batch_device(c, local[0].kind, d_part, span, d_units, n, d_out + arena_base, arena_room, d_res);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(res, d_res, n * sizeof(semz_result), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; i++) {
+            res[i].in_end_bit += 8 * r.in_lo;
+            distrust[r.first + i] = (uint8_t)(clamped[i] && res[i].status != SEMZ_OK);
+        }
+        return 0;
+    }
     // One range of the batch on a helper device, in a thread of its own: upload of the range's bytes, the same
     // kernels, results back in the frame of the batch (multi.h).  The output stays in the helper's arena.
     int decode_on_helper(Helper &h, unsigned tag, const semz_unit *units, const MultiRange &r, uint64_t frame_base, semz_result *res)
@@ -276,6 +332,7 @@ struct Run {
             HIPCHK(hc, e);
         }
         HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
+        uploaded += span;
         if (r.out_room > (SIZE_MAX >> 2)) return RC_OOM;
         if (h.out_used + r.out_room + 64 > h.out_cap) {
             size_t ncap = h.out_used + (size_t)r.out_room + 64;
@@ -404,6 +461,7 @@ struct Run {
             HIPCHK(hc, e);
         }
         HIPCHK(hc, hipMemcpyAsync(h.d_in, in + r.in_lo, span, hipMemcpyHostToDevice, hc->stream));
+        uploaded += span;
         std::vector<semz_unit> local;
         std::vector<uint8_t> clamped;
         localise_units(units, r, local, clamped);
@@ -524,7 +582,9 @@ struct Run {
     {
         (void)hipStreamSynchronize(c->stream);
         semz_pool_give(c, d_in, d_in_cap);
-        d_in_cap = 0;
+        semz_pool_give(c, d_part, d_part_cap);
+        d_part = nullptr;
+        d_in_cap = d_part_cap = 0;
         if (d_units) (void)hipFree(d_units);
         if (d_res) (void)hipFree(d_res);
         d_in = nullptr; d_units = nullptr; d_res = nullptr; unit_cap = 0;
@@ -581,7 +641,6 @@ struct Run {
     int read(uint64_t off, uint8_t *dst, uint64_t len)
     {
         if (off > emitted || len > emitted - off) return semz_fail(c, -1, "semz_stream_read: range beyond the decoded stream");
-        std::vector<uint8_t> used(helpers.size(), 0);
         // Windows of the batch loop are in host memory already, and when the call decodes into the caller's buffer
         // most of them are where they belong.  The ones that are not (the walk did not take the prediction as it
         // was) may lie where other spans have to go: they are set aside first.
@@ -604,6 +663,10 @@ struct Run {
                 at += sp.len;
             }
         }
+        // what comes from which device: the spans of one device go down one after the other, the devices side by
+        // side, each on a host thread of its own (every device has its own link to the host)
+        struct Copy { uint8_t *dst; const uint8_t *src; uint64_t len; };
+        std::vector<std::vector<Copy>> per_dev(helpers.size() + 1);
         uint64_t at = 0;
         for (auto &sp : spans) {
             if (!len) break;
@@ -613,27 +676,31 @@ struct Run {
                 if (dev == WINDOW_TAG) {
                     const HostChunk &k = chunks[multi_off(sp.off) >> WINDOW_SHIFT];
                     if (k.owned) memcpy(dst, k.p + (multi_off(sp.off) & ((1ull << WINDOW_SHIFT) - 1)) + skip, take);
-                } else if (dev == 0) {
-                    int rc = download(c, dst, d_out + sp.off + skip, take);
-                    if (rc) return rc;
-                } else {
-                    Helper &h = helpers[dev - 1];
-                    HIPCHK(c, hipSetDevice(h.c->device));
-                    int rc = download(h.c, dst, h.d_out + multi_off(sp.off) + skip, take);
-                    if (rc) return semz_fail(c, rc, "device %d: %s", h.c->device, h.c->err);
-                    used[dev - 1] = 1;
-                }
+                } else if (dev == 0) per_dev[0].push_back(Copy{dst, d_out + sp.off + skip, take});
+                else if (dev <= helpers.size()) per_dev[dev].push_back(Copy{dst, helpers[dev - 1].d_out + multi_off(sp.off) + skip, take});
+                else return semz_fail(c, -4, "internal: span on device %u", dev);
                 dst += take; off += take; len -= take;
             }
             at += sp.len;
         }
-        for (size_t i = 0; i < helpers.size(); i++)
-            if (used[i]) {
-                HIPCHK(c, hipSetDevice(helpers[i].c->device));
-                HIPCHK(c, hipStreamSynchronize(helpers[i].c->stream));
+        std::vector<int> rcs(per_dev.size(), 0);
+        auto run_dev = [&](size_t d) {
+            semz_ctx *x = d ? helpers[d - 1].c : c;
+            if (hipSetDevice(x->device) != hipSuccess) { rcs[d] = semz_fail(x, -2, "hipSetDevice failed"); return; }
+            for (auto &k : per_dev[d]) {
+                int rc = download(x, k.dst, k.src, k.len);
+                if (rc) { rcs[d] = rc; return; }
             }
+            if (hipStreamSynchronize(x->stream) != hipSuccess) rcs[d] = semz_fail(x, -2, "hipStreamSynchronize failed");
+        };
+        std::vector<std::thread> th;
+        for (size_t d = 1; d < per_dev.size(); d++)
+            if (!per_dev[d].empty()) th.emplace_back(run_dev, d);
+        run_dev(0);
+        for (auto &t : th) t.join();
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (size_t d = 0; d < per_dev.size(); d++)
+            if (rcs[d]) return d ? semz_fail(c, rcs[d], "device %d: %s", helpers[d - 1].c->device, helpers[d - 1].c->err) : rcs[d];
         for (auto &m : moved) memcpy(m.dst, m.bytes.data(), m.bytes.size());
         c->last_moved = moved.size();
         return 0;
@@ -1334,6 +1401,7 @@ static int stream_decode(semz_ctx *c, int fmt, const uint8_t *in, size_t in_len,
     if (rc) { delete Rp; return rc; }
     const double t2 = now();
     c->last_windows = R.windows_run;
+    c->last_uploaded = R.uploaded.load();
     R.drop_working_set();
     if (trace) fprintf(stderr, "semz_stream_decode: open+upload %.1f ms, split+decode %.1f ms, drop %.1f ms, %zu windows\n", t1 - t0, t2 - t1, now() - t2, R.windows_run);
     res->status = oc.status;

@@ -129,11 +129,12 @@ int semz_open(int device, semz_ctx **ctx);
 /* One input, several GPUs, inside the C call (the reference has no counterpart, its unit of
  * parallelism is the caller's thread): devices[0] is the primary device and behaves as a context from semz_open;
  * the stream calls (semz_decode_stream, semz_decode_stream_into, semz_stream_decode / read / release) split the
- * input once on the host, cut the predicted batch into contiguous ranges of about equal compressed size, decode
- * every range on its own device from the bytes of that range only (one host thread and one HIP stream per device,
+ * input once on the host, cut the predicted batch into contiguous ranges of about equal work (output bytes where
+ * the sizes are known -- gzip ISIZE, the xz index --, compressed bytes otherwise), decode every range on its own
+ * device, the primary included, from the bytes of that range only (one host thread and one HIP stream per device,
  * no data-path collective) and walk the merged results in the reference's order.  Units the walk has to decode
  * on demand, and a failed unit whose input span was cut at a range boundary, are decoded on the primary device,
- * which holds the whole input.  The batch calls (semz_decode_batch*) use the primary device only.  A device may be
+ * which takes the whole input then and only then.  The batch calls (semz_decode_batch*) use the primary device only.  A device may be
  * named more than once (two contexts on one GPU).  semz_close closes all of them. */
 int semz_open_multi(const int *devices, int ndev, semz_ctx **ctx);
 int semz_device_count(const semz_ctx *ctx);        /* 1 for semz_open, ndev for semz_open_multi */
@@ -202,7 +203,10 @@ int semz_set_option(semz_ctx *ctx, const char *name, long value);
 /* Reads "batch-budget", "profile", "window-size" back, and "windows": the number of windows the last stream
  * call on this context decoded (0 = its batch went in one piece), and "moved": how many pieces of such windows
  * the last read found in the caller's buffer at another place than the stream has them (the walk did not take
- * the prediction as it was) and moved.  No counterpart in the reference. */
+ * the prediction as it was) and moved, and "uploaded-bytes": the bytes of input the last stream call sent to
+ * devices, all devices of a semz_open_multi context together (every device gets the bytes of its own range; the
+ * whole input goes to the primary device only when the walk has to decode something by itself).  No counterpart
+ * in the reference. */
 int semz_get_option(semz_ctx *ctx, const char *name, long *value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */

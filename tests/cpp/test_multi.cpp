@@ -53,6 +53,17 @@ static void check(size_t n, unsigned parts, bool fixed, bool fail_cut)
     assert(at == n);
     if (ranges.size() == parts && n >= 4 * parts)
         for (auto &r : ranges) assert(r.count + 2 >= n / parts && r.count <= n / parts + 2);
+    // no device -- the primary (range 0) included -- is handed more of the input than its own units' bytes and the
+    // margin: together the devices upload the input once, plus a margin per cut
+    uint64_t uploaded = 0;
+    for (size_t p = 0; p < ranges.size(); p++) {
+        const MultiRange &r = ranges[p];
+        const uint64_t own_hi = p + 1 < ranges.size() ? u[ranges[p + 1].first].in_off : in_len;
+        assert(r.in_hi - r.in_lo <= (own_hi - r.in_lo) + 64);
+        if (ranges.size() > 1) assert(r.in_hi - r.in_lo < in_len);
+        uploaded += r.in_hi - r.in_lo;
+    }
+    assert(uploaded <= in_len + 64 * ranges.size());
     std::vector<semz_result> res(n);
     std::vector<uint8_t> distrust(n, 0xAA);
     for (size_t p = 0; p < ranges.size(); p++) {
@@ -84,6 +95,42 @@ static void check(size_t n, unsigned parts, bool fixed, bool fail_cut)
             const bool cut = u[i].in_limit > ranges[p].in_hi;
             assert(distrust[i] == (uint8_t)(fail_cut && cut));
         }
+}
+
+// Ranges are balanced by output bytes where every unit's size is known (fixed spans), by compressed bytes otherwise:
+// units whose output sizes differ a hundredfold while their compressed sizes are alike.
+static void check_balance()
+{
+    const size_t n = 400;
+    const uint64_t in_len = 1000 * n;
+    for (int fixed = 0; fixed < 2; fixed++) {
+        std::vector<semz_unit> u;
+        uint64_t out = 0, total = 0;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t cap = i < n / 4 ? 100000 : 1000;           // the first quarter holds most of the output
+            u.push_back(unit(1000 * i, in_len, fixed ? out : SEMZ_OUT_AUTO, fixed ? cap : 0));
+            out += cap;
+            total += cap;
+        }
+        auto ranges = partition_units(u.data(), n, in_len, 4, 64, total);
+        assert(ranges.size() == 4);
+        if (fixed) {
+            for (auto &r : ranges) {
+                uint64_t w = 0;
+                for (size_t i = r.first; i < r.first + r.count; i++) w += u[i].out_cap;
+                assert(w + 100000 >= total / 4 && w <= total / 4 + 100000);
+            }
+            assert(ranges[0].count < n / 8);                          // far fewer units where the units are large
+        } else {
+            for (auto &r : ranges) assert(r.count == n / 4);
+        }
+    }
+    // sizes that are claims of the data and do not add up: back to compressed bytes, no overflow
+    std::vector<semz_unit> u;
+    for (size_t i = 0; i < 8; i++) u.push_back(unit(1000 * i, 8000, 0, ~0ull / 2));
+    auto ranges = partition_units(u.data(), 8, 8000, 4, 64, 0);
+    assert(ranges.size() == 4);
+    for (auto &r : ranges) assert(r.count == 2);
 }
 
 // the batch loop's windows: contiguous, complete, every one within the limit unless it is a single unit, and the
@@ -142,6 +189,7 @@ static void check_windows(size_t n, uint64_t limit, bool fixed, uint64_t unit_sc
 
 int main()
 {
+    check_balance();
     for (size_t n : {1, 2, 3, 7, 64, 1000})
         for (uint64_t limit : {1ull, 3000ull, 20000ull, 1ull << 40})
             for (int fixed = 0; fixed < 2; fixed++)

@@ -50,6 +50,23 @@ def test_gzip_members_spread(engines):
     assert want[0] == 0 and want[3] == b"".join(plain)
     for eng in (two, three):
         assert _decode(eng, _lib.FMT_GZIP, data) == want
+        # every device, the primary included, is sent the bytes of its own range and a margin: the input goes up once
+        assert len(data) <= eng.get_option("uploaded-bytes") <= len(data) + eng.device_count * (64 * 1024 + 64)
+    _decode(one, _lib.FMT_GZIP, data)
+    assert one.get_option("uploaded-bytes") == len(data)
+
+
+def test_ranges_follow_the_output_sizes(engines):
+    """Members of very different sizes: the ranges are cut by output bytes (ISIZE), SURVEY.md section 8e, so the
+    device that gets the large members gets few of them; results are those of one device."""
+    one, two, three = engines
+    plain = [corpus.text(900_000, seed=400 + i) for i in range(4)] + [corpus.text(20_000, seed=500 + i) for i in range(60)]
+    data = b"".join(gzip.compress(p, 6) for p in plain)
+    want = _decode(one, _lib.FMT_GZIP, data)
+    assert want[0] == 0 and want[3] == b"".join(plain)
+    for eng in (two, three):
+        assert _decode(eng, _lib.FMT_GZIP, data) == want
+        assert eng.get_option("uploaded-bytes") <= len(data) + eng.device_count * (64 * 1024 + 64)
 
 
 def test_gzip_damaged_member_in_second_range(engines):
