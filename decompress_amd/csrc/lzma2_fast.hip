@@ -25,8 +25,9 @@
 //    bit leaves "code < bound" in SCC, so s_addc_u32 q, q, q is the whole tree step, and the three
 //    selects of the range decoder hang on the same SCC.  Which lane holds which node is private
 //    to this kernel (every model starts at 1024), the decoded value is ~q.
-//  * The probability update is p - ((p - K) >> 5) with K = 2017 or 0, arithmetic shift: equal to
-//    p + ((2048 - p) >> 5) and p - (p >> 5) of lzma.lisp:104-112.
+//  * The probability update is (31 p + K) >> 5 with K = 2048 or 31: equal to p + ((2048 - p) >> 5) and
+//    p - (p >> 5) of lzma.lisp:104-112 (31 p + 2048 = 32 p + (2048 - p); 31 p + 31 = 32 p - (p - 31), and
+//    ceil((p - 31) / 32) = floor(p / 32)), one multiply-add and one shift on the vector pipe.
 //  * The check "code < range" after a normalisation (lzma.lisp:72-73) cannot fail once it held at
 //    the start (code < range implies 256 code + byte < 256 range), so only the start and the one
 //    case of the direct bits that can break the invariant (lzma.lisp:186-188) are tested.
@@ -74,11 +75,10 @@ __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); 
     "s_sub_u32 %[nc], %[code], %[b]\n\t" /* SCC = code < bound: 0 */    \
     "s_cselect_b32 %[range], %[b], %[nr]\n\t"                           \
     "s_cselect_b32 %[code], %[code], %[nc]\n\t"                         \
-    "s_cselect_b32 %[k], 0x7e1, 0\n\t"
+    "s_cselect_b32 %[k], 0x800, 31\n\t"
 #define A_BIT_TAIL(vt)                                                  \
-    "v_sub_u32_e64 %[t], " vt ", %[k]\n\t"                              \
-    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
-    "v_sub_u32_e32 %[t], " vt ", %[t]\n\t"                              \
+    "v_mad_u32_u24 %[t], " vt ", 31, %[k]\n\t"                          \
+    "v_lshrrev_b32_e32 %[t], 5, %[t]\n\t"                               \
     "v_cndmask_b32_e64 " vt ", " vt ", %[t], %[mq]\n\t"
 #define A_NORM                                                          \
     "s_cmp_gt_u32 %[range], 0xffffff\n\t"                               \
@@ -110,15 +110,13 @@ __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); 
     "s_sub_u32 %[nc], %[code], %[b]\n\t"                                \
     "s_cselect_b32 %[range], %[b], %[nr]\n\t"                           \
     "s_cselect_b32 %[code], %[code], %[nc]\n\t"                         \
-    "s_cselect_b32 %[k], 0x7e1, 0\n\t"                                  \
+    "s_cselect_b32 %[k], 0x800, 31\n\t"                                 \
     "s_addc_u32 m0, m0, m0\n\t"                                         \
-    "v_sub_u32_e64 %[t], " va ", %[k]\n\t"                              \
-    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
-    "v_sub_u32_e32 %[t], " va ", %[t]\n\t"                              \
+    "v_mad_u32_u24 %[t], " va ", 31, %[k]\n\t"                          \
+    "v_lshrrev_b32_e32 %[t], 5, %[t]\n\t"                               \
     "v_cndmask_b32_e64 " va ", " va ", %[t], %[mq]\n\t"                 \
-    "v_sub_u32_e64 %[t], " vb ", %[k]\n\t"                              \
-    "v_ashrrev_i32_e32 %[t], 5, %[t]\n\t"                               \
-    "v_sub_u32_e32 %[t], " vb ", %[t]\n\t"                              \
+    "v_mad_u32_u24 %[t], " vb ", 31, %[k]\n\t"                          \
+    "v_lshrrev_b32_e32 %[t], 5, %[t]\n\t"                               \
     "v_cndmask_b32_e64 " vb ", " vb ", %[t], %[mb]\n\t" A_NORM
 #define A_RC_OUT [range] "+s"(range), [code] "+s"(code), [off] "+s"(off), [p] "=&s"(p), [b] "=&s"(b), [nr] "=&s"(nr), \
                  [nc] "=&s"(nc), [k] "=&s"(k), [mq] "=&s"(mq), [t] "=&v"(t)
@@ -220,6 +218,241 @@ __device__ __forceinline__ uint32_t direct_bits(uint32_t n, uint32_t &range, uin
                  : [win] "v"(win)
                  : "scc");
     return hi;
+}
+
+// ---- one LZMA symbol, decoded by ONE block of assembler ----
+// Between the bit runs above the compiler used to write the symbol's state machine: which flag comes next, which
+// tree, the rep rotation, the state update.  With the models as read-write operands of many small blocks under C++
+// control flow that was copies of model registers around every join, booleans kept as lane masks and spilled, and
+// about 150 instructions of glue per symbol (33 M of a 1 MiB block's 84 M).  The whole decision tree of a symbol
+// (lzma.lisp:566-775 without the LZ copies) is now straight assembler: is-literal; the literal's eight-level tree
+// (after a literal: its context's subtree is read from LDS at the top and written back at the end); is-simple,
+// the length decoders with their high trees in LDS, the slot tree, the reverse trees of slots 4..13, the direct
+// bits and the align tree; the rep flags with the rotation of rep0..rep3; the state table (lzma.lisp:615).  What
+// comes out: kind 0 = literal (val = the byte), 1 = a literal that follows a match (only its flag is decoded: the
+// matched walk needs the match byte, which may still be on its way from HBM, so the C++ code below takes over),
+// 2 = match (val = length; rep0 and state are updated).  `bad` = the one failure of the direct bits
+// (lzma.lisp:186-188) or an end marker; the caller hands the unit to the general kernel.
+// Labels: 1 belongs to A_NORM; 10..99 are this block's.
+#define A_FLAG(vt) A_BIT_HEAD(vt) "s_cselect_b32 %[f], 1, 0\n\t" A_BIT_TAIL(vt) A_NORM "s_cmp_eq_u32 %[f], 0\n\t"
+#define A_TREE6(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt)
+#define A_LDS_TREE8_IN(addr) "ds_read_u16 %[v0], " addr "\n\tds_read_u16 %[v1], " addr " offset:128\n\t" \
+                             "ds_read_u16 %[v2], " addr " offset:256\n\tds_read_u16 %[v3], " addr " offset:384\n\t"
+#define A_LDS_TREE8_OUT(addr) "ds_write_b16 " addr ", %[v0]\n\tds_write_b16 " addr ", %[v1] offset:128\n\t" \
+                              "ds_write_b16 " addr ", %[v2] offset:256\n\tds_write_b16 " addr ", %[v3] offset:384\n\t"
+#define A_TREE8 "s_mov_b32 m0, 1\n\t" A_TREE6("%[v0]") A_TREE("%[v1]") A_LEVEL7("%[v2]", "%[v3]")
+// decode-lzma-length (lzma.lisp:247-257): low tree and the two choices in w0, mid tree in w1, high tree in LDS at
+// %[highb] + hoff; leaves the length code 0..271 in %[val].  la / lb / lc: three labels of this expansion.
+#define A_LENGTH(w0, w1, hoff, la, lb, lc)                                                                          \
+    "s_lshl_b32 %[base], %[ps], 3\n\t"                                                                              \
+    "s_mov_b32 m0, 32\n\t" A_FLAG(w0)                                                                               \
+    "s_cbranch_scc1 " la "f\n\t"                                                                                    \
+    "s_mov_b32 %[q], 1\n\t" A_TREEB(w0) A_TREEB(w0) A_TREEB(w0)                                                     \
+    "s_andn2_b32 %[val], 7, %[q]\n\t"                                                                               \
+    "s_branch " lc "f\n"                                                                                            \
+    la ":\n\t"                                                                                                      \
+    "s_mov_b32 m0, 33\n\t" A_FLAG(w0)                                                                               \
+    "s_cbranch_scc1 " lb "f\n\t"                                                                                    \
+    "s_mov_b32 %[q], 1\n\t" A_TREEB(w1) A_TREEB(w1) A_TREEB(w1)                                                     \
+    "s_andn2_b32 %[val], 7, %[q]\n\t"                                                                               \
+    "s_add_u32 %[val], %[val], 8\n\t"                                                                               \
+    "s_branch " lc "f\n"                                                                                            \
+    lb ":\n\t"                                                                                                      \
+    "v_add_u32_e32 %[tv], %[highb] + " hoff ", %[l2]\n\t"                                                            \
+    A_LDS_TREE8_IN("%[tv]") "s_waitcnt lgkmcnt(0)\n\t" A_TREE8 A_LDS_TREE8_OUT("%[tv]")                             \
+    "s_andn2_b32 %[val], 0xff, m0\n\t"                                                                              \
+    "s_add_u32 %[val], %[val], 16\n"                                                                                \
+    lc ":\n\t"
+
+#ifdef SEMZ_STAMPS
+// diagnostic build only (make STAMPS=1): shader-clock totals per phase summed over all units (scripts/lzma_stamps.py)
+__device__ unsigned long long g_lz_stamps[16];
+#define LZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
+#define LZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#define LZ_COUNT(i) (n_acc[i]++)
+#else
+#define LZ_STAMP_DECL
+#define LZ_STAMP(i) do { } while (0)
+#define LZ_COUNT(i) do { } while (0)
+#endif
+
+struct Symbol { uint32_t kind, val, bad; };
+
+__device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code, uint32_t &off, uint32_t win, uint32_t &state,
+                                                uint32_t &rep0, uint32_t &rep1, uint32_t &rep2, uint32_t &rep3, uint32_t ps,
+                                                uint32_t &vA, uint32_t &vB, uint32_t &vC, uint32_t &vS0, uint32_t &vS1,
+                                                uint32_t &vR0, uint32_t &vR1, uint32_t lit_addr, uint32_t lane2)
+{
+    // (the kernel's LDS block starts at address 0, which the kernel checks once: the trees' addresses are immediates)
+    constexpr uint32_t slotb = __builtin_offsetof(FastLds, slot), midb = __builtin_offsetof(FastLds, mid),
+                       highb = __builtin_offsetof(FastLds, high);
+    A_TEMPS;
+    uint64_t mb;
+    uint32_t kind, val, bad, f, x, y, base, q, v0, v1, v2, v3, tv;
+    asm volatile(
+        // ---- is-literal [state * 4 + pos_state]; after a literal the context's subtree is on its way meanwhile ----
+        "s_lshl_b32 %[x], %[st], 2\n\t"
+        "s_mov_b32 %[bad], 0\n\t"
+        "s_add_u32 m0, %[x], %[ps]\n\t"
+        "s_cmp_gt_u32 %[st], 6\n\t"
+        "s_cbranch_scc1 10f\n\t"
+        A_LDS_TREE8_IN("%[la]")
+        "10:\n\t"
+        A_FLAG("%[vA]")
+        "s_cbranch_scc1 20f\n\t"
+        // ---- literal (lzma.lisp:661-688) ----
+        "s_mov_b32 %[kind], 1\n\t"
+        "s_cmp_gt_u32 %[st], 6\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        A_TREE8
+        A_LDS_TREE8_OUT("%[la]")
+        "s_andn2_b32 %[val], 0xff, m0\n\t"
+        "s_sub_u32 %[x], %[st], 3\n\t"
+        "s_cmp_lt_u32 %[st], 4\n\t"
+        "s_cselect_b32 %[st], 0, %[x]\n\t"
+        "s_mov_b32 %[kind], 0\n\t"
+        "s_branch 99f\n"
+        // ---- match: is-simple [state] ----
+        "20:\n\t"
+        "s_mov_b32 m0, %[st]\n\t"
+        A_FLAG("%[vC]")
+        "s_cbranch_scc1 40f\n\t"
+        // simple match: length, then distance (lzma.lisp:323-341)
+        A_LENGTH("%[vS0]", "%[vS1]", "0", "21", "22", "23")
+        "s_cmp_lt_u32 %[st], 7\n\t"
+        "s_cselect_b32 %[st], 7, 10\n\t"
+        "s_mov_b32 %[r3], %[r2]\n\t"
+        "s_mov_b32 %[r2], %[r1]\n\t"
+        "s_mov_b32 %[r1], %[r0]\n\t"
+        "s_min_u32 %[x], %[val], 3\n\t"
+        "s_lshl_b32 %[x], %[x], 7\n\t"
+        "s_add_u32 %[x], %[x], %[slotb]\n\t"
+        "v_add_u32_e32 %[tv], %[x], %[l2]\n\t"
+        "ds_read_u16 %[v0], %[tv]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 m0, 1\n\t"
+        A_TREE6("%[v0]")
+        "ds_write_b16 %[tv], %[v0]\n\t"
+        "s_andn2_b32 %[x], 63, m0\n\t"                   // the slot
+        "s_mov_b32 %[r0], %[x]\n\t"
+        "s_cmp_lt_u32 %[x], 4\n\t"
+        "s_cbranch_scc1 30f\n\t"
+        "s_lshr_b32 %[y], %[x], 1\n\t"
+        "s_sub_u32 %[y], %[y], 1\n\t"                    // nb
+        "s_and_b32 %[r0], %[x], 1\n\t"
+        "s_or_b32 %[r0], %[r0], 2\n\t"
+        "s_lshl_b32 %[r0], %[r0], %[y]\n\t"              // min_dist
+        "s_cmp_lt_u32 %[x], 14\n\t"
+        "s_cbranch_scc0 27f\n\t"
+        // slots 4..13: a reverse tree of nb = 1..5 bits, least significant first
+        "s_sub_u32 %[x], %[x], 4\n\t"
+        "s_lshl_b32 %[x], %[x], 7\n\t"
+        "s_add_u32 %[x], %[x], %[midb]\n\t"
+        "v_add_u32_e32 %[tv], %[x], %[l2]\n\t"
+        "ds_read_u16 %[v1], %[tv]\n\t"
+        "s_mov_b32 %[x], %[y]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 m0, 1\n"
+        "25:\n\t"
+        A_TREE("%[v1]")
+        "s_sub_u32 %[x], %[x], 1\n\t"
+        "s_cmp_lg_u32 %[x], 0\n\t"
+        "s_cbranch_scc1 25b\n\t"
+        "ds_write_b16 %[tv], %[v1]\n\t"
+        "s_not_b32 %[x], m0\n\t"
+        "s_bfm_b32 %[f], %[y], 0\n\t"
+        "s_and_b32 %[x], %[x], %[f]\n\t"
+        "s_brev_b32 %[x], %[x]\n\t"
+        "s_sub_u32 %[f], 32, %[y]\n\t"
+        "s_lshr_b32 %[x], %[x], %[f]\n\t"
+        "s_add_u32 %[r0], %[r0], %[x]\n\t"
+        "s_branch 30f\n"
+        // slots 14..63: nb - 4 direct bits (lzma.lisp:174-192), then the four align bits
+        "27:\n\t"
+        "s_sub_u32 %[x], %[y], 4\n\t"
+        "s_mov_b32 %[f], 0\n"
+        "28:\n\t"
+        "s_lshr_b32 %[range], %[range], 1\n\t"
+        "s_sub_u32 %[b], %[code], %[range]\n\t"          // SCC = code < range: the bit is 0
+        "s_cselect_b32 %[code], %[code], %[b]\n\t"
+        "s_addc_u32 %[f], %[f], %[f]\n\t"
+        "s_cmp_eq_u32 %[code], %[range]\n\t"
+        "s_cmov_b32 %[bad], 1\n\t"
+        A_NORM
+        "s_sub_u32 %[x], %[x], 1\n\t"
+        "s_cmp_lg_u32 %[x], 0\n\t"
+        "s_cbranch_scc1 28b\n\t"
+        "s_sub_u32 %[x], %[y], 4\n\t"
+        "s_bfm_b32 %[x], %[x], 0\n\t"
+        "s_andn2_b32 %[f], %[x], %[f]\n\t"
+        "s_lshl_b32 %[f], %[f], 4\n\t"
+        "s_add_u32 %[r0], %[r0], %[f]\n\t"
+        "s_mov_b32 %[base], 48\n\t"
+        "s_mov_b32 %[q], 1\n\t"
+        A_TREEB("%[vC]") A_TREEB("%[vC]") A_TREEB("%[vC]") A_TREEB("%[vC]")
+        "s_andn2_b32 %[x], 15, %[q]\n\t"
+        "s_brev_b32 %[x], %[x]\n\t"
+        "s_lshr_b32 %[x], %[x], 28\n\t"
+        "s_add_u32 %[r0], %[r0], %[x]\n"
+        "30:\n\t"
+        "s_cmp_eq_u32 %[r0], -1\n\t"                     // an end marker is illegal in LZMA2 (lzma.lisp:727-732)
+        "s_cmov_b32 %[bad], 1\n\t"
+        "s_add_u32 %[val], %[val], 2\n\t"
+        "s_mov_b32 %[kind], 2\n\t"
+        "s_branch 99f\n"
+        // ---- rep matches: uses-rep0 [12 + state] ----
+        "40:\n\t"
+        "s_add_u32 m0, %[st], 12\n\t"
+        A_FLAG("%[vC]")
+        "s_cbranch_scc1 44f\n\t"
+        "s_lshl_b32 %[x], %[st], 2\n\t"
+        "s_add_u32 m0, %[x], %[ps]\n\t"
+        A_FLAG("%[vB]")                                  // is-short-rep [state * 4 + pos_state]
+        "s_cbranch_scc1 47f\n\t"
+        "s_cmp_lt_u32 %[st], 7\n\t"
+        "s_cselect_b32 %[st], 9, 11\n\t"
+        "s_mov_b32 %[val], 1\n\t"
+        "s_mov_b32 %[kind], 2\n\t"
+        "s_branch 99f\n"
+        "44:\n\t"
+        "s_add_u32 m0, %[st], 24\n\t"
+        A_FLAG("%[vC]")                                  // is-rep1 [24 + state]
+        "s_cbranch_scc1 45f\n\t"
+        "s_mov_b32 %[x], %[r1]\n\t"
+        "s_mov_b32 %[r1], %[r0]\n\t"
+        "s_mov_b32 %[r0], %[x]\n\t"
+        "s_branch 47f\n"
+        "45:\n\t"
+        "s_add_u32 m0, %[st], 36\n\t"
+        A_FLAG("%[vC]")                                  // is-rep2 [36 + state]
+        "s_cbranch_scc1 46f\n\t"
+        "s_mov_b32 %[x], %[r2]\n\t"
+        "s_mov_b32 %[r2], %[r1]\n\t"
+        "s_mov_b32 %[r1], %[r0]\n\t"
+        "s_mov_b32 %[r0], %[x]\n\t"
+        "s_branch 47f\n"
+        "46:\n\t"
+        "s_mov_b32 %[x], %[r3]\n\t"
+        "s_mov_b32 %[r3], %[r2]\n\t"
+        "s_mov_b32 %[r2], %[r1]\n\t"
+        "s_mov_b32 %[r1], %[r0]\n\t"
+        "s_mov_b32 %[r0], %[x]\n"
+        "47:\n\t"
+        "s_cmp_lt_u32 %[st], 7\n\t"
+        "s_cselect_b32 %[st], 8, 11\n\t"
+        A_LENGTH("%[vR0]", "%[vR1]", "512", "41", "42", "43")
+        "s_add_u32 %[val], %[val], 2\n\t"
+        "s_mov_b32 %[kind], 2\n"
+        "99:\n\t"
+        : [vA] "+v"(vA), [vB] "+v"(vB), [vC] "+v"(vC), [vS0] "+v"(vS0), [vS1] "+v"(vS1), [vR0] "+v"(vR0), [vR1] "+v"(vR1),
+          [st] "+s"(state), [r0] "+s"(rep0), [r1] "+s"(rep1), [r2] "+s"(rep2), [r3] "+s"(rep3), A_RC_OUT, [mb] "=&s"(mb),
+          [kind] "=&s"(kind), [val] "=&s"(val), [bad] "=&s"(bad), [f] "=&s"(f), [x] "=&s"(x), [y] "=&s"(y), [base] "=&s"(base),
+          [q] "=&s"(q), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [tv] "=&v"(tv)
+        : [win] "v"(win), [ps] "s"(ps), [la] "v"(lit_addr), [l2] "v"(lane2), [slotb] "i"(slotb), [midb] "i"(midb),
+          [highb] "i"(highb)
+        : "scc", "m0", "memory");
+    return Symbol{kind, val, bad};
 }
 
 // Input: 256 bytes of the unit's compressed data sit in one register, a dword per lane; `off` counts bytes from
@@ -332,6 +565,7 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     uint32_t p = 0, dict_base = 0, flushed = 0;
     bool ok = true;                 // false: hand the unit to the general kernel
 
+    LZ_STAMP_DECL
     auto flush = [&](bool all) {
         semz_take_turn(16);                      // (semz_device.h: the two units of a SIMD end together; 0.65 ms a turn)
         const uint32_t head = (16 - shift) & 15;
@@ -373,9 +607,8 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     };
 #define PIN_ALL()                                                                                                       \
     do {                                                                                                                \
-        range = uni(range); code = uni(code); p = uni(p); total = uni(total); state = uni(state); rep0 = uni(rep0);     \
-        rep1 = uni(rep1); rep2 = uni(rep2); rep3 = uni(rep3); prev = uni(prev); flushed = uni(flushed);                 \
-        dict_base = uni(dict_base); s.off = uni(s.off); s.wbase = uni(s.wbase);                                         \
+        p = uni(p); total = uni(total); prev = uni(prev); flushed = uni(flushed);                                       \
+        dict_base = uni(dict_base); s.wbase = uni(s.wbase);                                                             \
     } while (0)
 #define BIT(vt, sel) (q = bitq(vt, sel, range, code, s.off, s.v, q))
 
@@ -386,8 +619,14 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     // (what a literal right behind the match is matched against).
     uint32_t pend_len = 0, pend_p = 0, pend_sh = 0, pend_l = 0;
     const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)L.stage;
+    // (byte addresses in LDS of the trees decode_symbol reads and writes)
+    constexpr uint32_t lit_lds = __builtin_offsetof(FastLds, lit);
+    const uint32_t lane2 = 2 * lane;
+    if (uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.ring) != 0) { retry(); return; }   // (see decode_symbol)
     auto resolve = [&]() -> uint32_t {                    // returns the bytes, one per lane
+        LZ_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the load below is not one the compiler knows of)
+        LZ_STAMP(1);
         const uint32_t w = L.stage[lane];
         const uint32_t bv = pend_sh < 32 ? (w >> pend_sh) & 0xFF : pend_l;
         if (lane < pend_len) L.ring[(pend_p + lane + shift) & F_MASK] = (uint8_t)bv;
@@ -485,21 +724,18 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
             PIN_ALL();
             s.slide();
             const uint32_t ps = total & pb_mask;
-            uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, lbase = 0;
-            const bool after_literal = state < 7;
-            if (after_literal) {
-                // the literal subtree of this context, on its way while the is-literal bit is decoded
-                lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
-                const uint16_t *t = L.lit + lbase + lane;
-                v0 = t[0]; v1 = t[64]; v2 = t[128]; v3 = t[192];
-            }
-            uint32_t q = 1;
-            BIT(vA, state * 4 + ps);
-            if (q == 3) {
-                // ---- literal (lzma.lisp:661-688) ----
-                if (after_literal) {
-                    q = tree8(v0, v1, v2, v3, range, code, s.off, s.v);
-                } else {
+            // (after a literal: the address of this context's literal subtree, lane by lane; decode_symbol reads it)
+            uint32_t lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
+            LZ_STAMP(7);
+            const Symbol sym = decode_symbol(range, code, s.off, s.v, state, rep0, rep1, rep2, rep3, ps, vA, vB, vC, vS0, vS1, vR0,
+                                             vR1, lit_lds + 2 * lbase + lane2, lane2);
+            LZ_STAMP(0);
+            LZ_COUNT(sym.kind);
+            if (sym.bad) { ok = false; break; }
+            if (sym.kind < 2) {
+                uint32_t byte = sym.val;
+                if (sym.kind == 1) {
+                    // ---- a literal behind a match (lzma.lisp:497-518): walk the match byte's path while the bits agree ----
                     uint32_t mb;
                     if (pend_len) {
                         const uint32_t n = uni(pend_len);
@@ -519,10 +755,9 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
                     join_lanes();
                     uint16_t *mt = L.lit + lbase + node;
                     uint32_t vm = *mt;
-                    const uint16_t *t = L.lit + lbase + lane;
-                    v0 = t[0]; v1 = t[64]; v2 = t[128]; v3 = t[192];
-                    // decode-lzma-literal/match-case, lzma.lisp:497-518: follow the match byte while the bits agree
-                    q = 1;
+                    uint16_t *t = L.lit + lbase + lane;
+                    uint32_t v0 = t[0], v1 = t[64], v2 = t[128], v3 = t[192];
+                    uint32_t q = 1;
                     uint32_t lvl = 0;
                     for (; lvl < 8; lvl++) {
                         const uint32_t want = 2 * q + (((mb >> (7 - lvl)) & 1) ^ 1);
@@ -541,110 +776,29 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
                     case 7: q = level7(v2, v3, range, code, s.off, s.v, q); break;
                     default: break;
                     }
-                }
-                {
-                    uint16_t *t = L.lit + lbase + lane;
                     t[0] = (uint16_t)v0; t[64] = (uint16_t)v1; t[128] = (uint16_t)v2; t[192] = (uint16_t)v3;
+                    byte = ~q & 0xFF;
+                    state = state < 10 ? state - 3 : state - 6;          // lzma.lisp:615 (state >= 7 here)
                 }
                 if (s.pos() > chunk_end) { ok = false; break; }
-                const uint32_t byte = ~q & 0xFF;
                 L.ring[(p + shift) & F_MASK] = (uint8_t)byte;        // every lane: same address, same value
                 prev = byte;
                 p++;
                 total++;
-                state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;   // lzma.lisp:615
-                if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); flush(false); }
+                if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); LZ_STAMP(2); flush(false); LZ_STAMP(3); }
+                LZ_STAMP(2);
                 continue;
             }
             // ---- match ----
-            uint32_t len;
-            // length decoder (lzma.lisp:247-257) over the register pair (low + choices, mid) and the LDS high tree
-            auto length = [&](uint32_t &w0, uint32_t &w1, uint32_t kind) -> uint32_t {
-                uint32_t q = 1;
-                BIT(w0, 32);
-                if (q == 3) return ~walkb<3>(w0, ps * 8, range, code, s.off, s.v) & 7;
-                q = 1;
-                BIT(w0, 33);
-                if (q == 3) return 8 + (~walkb<3>(w1, ps * 8, range, code, s.off, s.v) & 7);
-                uint16_t *t = L.high + kind * 256 + lane;
-                uint32_t h0 = t[0], h1 = t[64], h2 = t[128], h3 = t[192];
-                q = tree8(h0, h1, h2, h3, range, code, s.off, s.v);
-                t[0] = (uint16_t)h0; t[64] = (uint16_t)h1; t[128] = (uint16_t)h2; t[192] = (uint16_t)h3;
-                return 16 + (~q & 0xFF);
-            };
-            q = 1;
-            BIT(vC, state);
-            if (q == 3) {
-                // simple match: length, then distance (lzma.lisp:323-341)
-                const uint32_t rl = length(vS0, vS1, 0);
-                state = state < 7 ? 7 : 10;
-                rep3 = rep2; rep2 = rep1; rep1 = rep0;
-                uint16_t *st = L.slot + 64 * (rl < 3 ? rl : 3) + lane;
-                uint32_t vs = *st;
-                q = walk<6>(vs, range, code, s.off, s.v, 1);
-                *st = (uint16_t)vs;
-                const uint32_t slot = ~q & 63;
-                if (slot < 4) rep0 = slot;
-                else {
-                    const uint32_t nb = (slot >> 1) - 1;
-                    const uint32_t min_dist = (2u | (slot & 1)) << nb;
-                    if (slot < 14) {
-                        uint16_t *mt = L.mid + 64 * (slot - 4) + lane;
-                        uint32_t vd = *mt;
-                        q = 1;
-                        BIT(vd, q);                                      // one to five bits, least significant first
-                        if (nb > 1) BIT(vd, q);
-                        if (nb > 2) BIT(vd, q);
-                        if (nb > 3) BIT(vd, q);
-                        if (nb > 4) BIT(vd, q);
-                        *mt = (uint16_t)vd;
-                        rep0 = min_dist + (__brev(~q & ((1u << nb) - 1)) >> (32 - nb));
-                    } else {
-                        uint32_t bad = 0;
-                        uint32_t hi = direct_bits(nb - 4, range, code, s.off, s.v, bad);   // lzma.lisp:174-192
-                        if (bad) ok = false;
-                        hi = ~hi & ((1u << (nb - 4)) - 1);
-                        q = walkb<4>(vC, 48, range, code, s.off, s.v);
-                        rep0 = min_dist + (hi << 4) + (__brev(~q & 15) >> 28);
-                    }
-                }
-                if (rep0 == 0xFFFFFFFFu) { ok = false; break; }       // an end marker is illegal in LZMA2 (lzma.lisp:727-732)
-                len = rl + 2;
-            } else {
-                q = 1;
-                BIT(vC, 12 + state);
-                if (q == 3) {
-                    q = 1;
-                    BIT(vB, state * 4 + ps);
-                    if (q == 3) {
-                        state = state < 7 ? 9 : 11;
-                        len = 1;
-                    } else {
-                        state = state < 7 ? 8 : 11;
-                        len = 2 + length(vR0, vR1, 1);
-                    }
-                } else {
-                    uint32_t t;
-                    q = 1;
-                    BIT(vC, 24 + state);
-                    if (q == 3) { t = rep1; rep1 = rep0; rep0 = t; }
-                    else {
-                        q = 1;
-                        BIT(vC, 36 + state);
-                        if (q == 3) { t = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
-                        else { t = rep3; rep3 = rep2; rep2 = rep1; rep1 = rep0; rep0 = t; }
-                    }
-                    state = state < 7 ? 8 : 11;
-                    len = 2 + length(vR0, vR1, 1);
-                }
-            }
+            const uint32_t len = sym.val;
             if (!ok || s.pos() > chunk_end) { ok = false; break; }
             // handle-match, lzma.lisp:600-612
             if (rep0 >= dict_size || rep0 >= p - dict_base || len > endp - p) { ok = false; break; }
             // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
             if (pend_len) resolve();
-            if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); flush(false); }
+            if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); LZ_STAMP(4); flush(false); LZ_STAMP(3); }
             lds_sync();
+            LZ_STAMP(4);
             const uint32_t dist = rep0 + 1;
             const uint32_t src = p - dist;
             if (src + (F_RING - F_MAX_MATCH) > p + len) {
@@ -687,6 +841,7 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
                 pend_p = p;
                 p += len;
                 total += len;
+                LZ_COUNT(3);
             } else {
                 for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                     const uint32_t k = k0 + lane;
@@ -702,7 +857,9 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
                 total += len;
                 prev_v = L.ring[(p - 1 + shift) & F_MASK];
                 mbyte_v = history_byte_v(p - 1 - rep0);
+                LZ_COUNT(4);
             }
+            LZ_STAMP(5);
         }
         if (pend_len) resolve();
         if (!ok) break;
@@ -755,10 +912,28 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     if (lane == 0) {
         results[u] = r;
         tails[u] = t;
+#ifdef SEMZ_STAMPS
+        LZ_STAMP(6);
+        for (int i = 0; i < 8; i++) atomicAdd(&g_lz_stamps[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 6; i++) atomicAdd(&g_lz_stamps[8 + i], (unsigned long long)n_acc[i]);
+        atomicAdd(&g_lz_stamps[14], 1ull);
+#endif
     }
 }
 
 } // namespace
+
+#ifdef SEMZ_STAMPS
+extern "C" int semz_debug_lz_stamps(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lz_stamps), sizeof(g_lz_stamps)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lz_stamps), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 void semz_launch_lzma2_fast(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits, uint8_t *d_out,
                             size_t out_cap, semz_result *d_results, semz_tail *d_tails, hipStream_t stream)
