@@ -229,7 +229,10 @@ __device__ __forceinline__ uint32_t direct_bits(uint32_t n, uint32_t &range, uin
 // (after a literal: its context's subtree is read from LDS at the top and written back at the end); is-simple,
 // the length decoders with their high trees in LDS, the slot tree, the reverse trees of slots 4..13, the direct
 // bits and the align tree; the rep flags with the rotation of rep0..rep3; the state table (lzma.lisp:615).  What
-// comes out: kind 0 = literal (val = the byte), 1 = a literal that follows a match (only its flag is decoded: the
+// Literals that follow a literal are applied right here (ring, position, context of the next symbol) and the next
+// symbol is taken up at once, as long as the chunk goes on, the ring is not due for a flush and the input window
+// does not have to move.  What
+// comes out: kind 0 = the run ended behind a literal for one of those reasons, 1 = a literal that follows a match (only its flag is decoded: the
 // matched walk needs the match byte, which may still be on its way from HBM, so the C++ code below takes over),
 // 2 = match (val = length; rep0 and state are updated).  `bad` = the one failure of the direct bits
 // (lzma.lisp:186-188) or an end marker; the caller hands the unit to the general kernel.
@@ -270,7 +273,9 @@ __device__ unsigned long long g_lz_stamps[16];
 #define LZ_STAMP_DECL uint64_t t_last = __builtin_amdgcn_s_memtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint32_t n_acc[6] = {0, 0, 0, 0, 0, 0};
 #define LZ_STAMP(i) do { uint64_t t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
 #define LZ_COUNT(i) (n_acc[i]++)
+#define WHY(i) do { if (lane == 0) atomicAdd(&g_lz_stamps[15], 1ull << (8 * (i))); } while (0)
 #else
+#define WHY(i) do { } while (0)
 #define LZ_STAMP_DECL
 #define LZ_STAMP(i) do { } while (0)
 #define LZ_COUNT(i) do { } while (0)
@@ -278,21 +283,47 @@ __device__ unsigned long long g_lz_stamps[16];
 
 struct Symbol { uint32_t kind, val, bad; };
 
-__device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code, uint32_t &off, uint32_t win, uint32_t &state,
-                                                uint32_t &rep0, uint32_t &rep1, uint32_t &rep2, uint32_t &rep3, uint32_t ps,
-                                                uint32_t &vA, uint32_t &vB, uint32_t &vC, uint32_t &vS0, uint32_t &vS1,
-                                                uint32_t &vR0, uint32_t &vR1, uint32_t lit_addr, uint32_t lane2)
+// Position state of a run of symbols (decode_symbols): where the output stands and what ends the run.
+struct Run {
+    uint32_t p, total, prev;       // output position, total-i-mod-16 counter (not reduced here), last byte (valid after a literal)
+    uint32_t endp, flushed;        // end of the chunk's output; bytes of the ring that are in HBM already
+    uint32_t shift;                // ring index of output position 0
+    uint32_t lc, lc8, lp_mask, pb_mask;   // lc, 8 - lc, masks of lp and pb
+    uint32_t dict_size, dict_base; // lzma.lisp:600-612
+    uint32_t ob_low;               // low two bits of the unit's output address
+    uint64_t ob4;                  // that address rounded down to a dword
+    // the far match whose bytes are on their way (see the kernel): length (0 = none), position, per lane the shift of
+    // its byte inside the dword that was asked for (32 = the byte came from the ring) and that ring byte
+    uint32_t pend_len, pend_p, pend_sh, pend_l;
+};
+
+__device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code, uint32_t &off, uint32_t win, uint32_t &state,
+                                                 uint32_t &rep0, uint32_t &rep1, uint32_t &rep2, uint32_t &rep3, Run &r,
+                                                 uint32_t &vA, uint32_t &vB, uint32_t &vC, uint32_t &vS0, uint32_t &vS1,
+                                                 uint32_t &vR0, uint32_t &vR1, uint32_t lane2, uint32_t lane)
 {
     // (the kernel's LDS block starts at address 0, which the kernel checks once: the trees' addresses are immediates)
     constexpr uint32_t slotb = __builtin_offsetof(FastLds, slot), midb = __builtin_offsetof(FastLds, mid),
-                       highb = __builtin_offsetof(FastLds, high);
+                       highb = __builtin_offsetof(FastLds, high), litb = __builtin_offsetof(FastLds, lit),
+                       stageb = __builtin_offsetof(FastLds, stage);
+    uint32_t ps, la;
     A_TEMPS;
     uint64_t mb;
     uint32_t kind, val, bad, f, x, y, base, q, v0, v1, v2, v3, tv;
     asm volatile(
+        "s_mov_b32 %[bad], 0\n"
+        // ---- top of a symbol: pos_state, and (after a literal) the address of the context's literal subtree ----
+        "5:\n\t"
+        "s_and_b32 %[x], %[tot], %[lpm]\n\t"
+        "s_lshr_b32 %[y], %[prev], %[lc8]\n\t"
+        "s_lshl_b32 %[x], %[x], %[lc]\n\t"
+        "s_or_b32 %[x], %[x], %[y]\n\t"
+        "s_mulk_i32 %[x], 0x600\n\t"
+        "s_and_b32 %[ps], %[tot], %[pbm]\n\t"
+        "s_add_u32 %[x], %[x], %[litb]\n\t"
+        "v_add_u32_e32 %[la], %[x], %[l2]\n\t"
         // ---- is-literal [state * 4 + pos_state]; after a literal the context's subtree is on its way meanwhile ----
         "s_lshl_b32 %[x], %[st], 2\n\t"
-        "s_mov_b32 %[bad], 0\n\t"
         "s_add_u32 m0, %[x], %[ps]\n\t"
         "s_cmp_gt_u32 %[st], 6\n\t"
         "s_cbranch_scc1 10f\n\t"
@@ -307,11 +338,27 @@ __device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code,
         "s_waitcnt lgkmcnt(0)\n\t"
         A_TREE8
         A_LDS_TREE8_OUT("%[la]")
-        "s_andn2_b32 %[val], 0xff, m0\n\t"
+        "s_andn2_b32 %[prev], 0xff, m0\n\t"              // the byte
         "s_sub_u32 %[x], %[st], 3\n\t"
         "s_cmp_lt_u32 %[st], 4\n\t"
         "s_cselect_b32 %[st], 0, %[x]\n\t"
+        // the literal goes into the ring (every lane: same address, same value) and the next symbol follows at once
+        // unless the chunk is complete, the ring is due for a flush or the input window has to move
+        "s_add_u32 %[x], %[pp], %[shift]\n\t"
+        "s_and_b32 %[x], %[x], 0xfff\n\t"
+        "v_mov_b32_e32 %[tv], %[x]\n\t"
+        "v_mov_b32_e32 %[v0], %[prev]\n\t"
+        "s_add_u32 %[pp], %[pp], 1\n\t"
+        "s_add_u32 %[tot], %[tot], 1\n\t"
+        "ds_write_b8 %[tv], %[v0]\n\t"
         "s_mov_b32 %[kind], 0\n\t"
+        "s_cmp_eq_u32 %[pp], %[endp]\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_sub_u32 %[x], %[pp], %[fl]\n\t"
+        "s_cmp_ge_u32 %[x], 0x410\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_cmp_lt_u32 %[off], 192\n\t"
+        "s_cbranch_scc1 5b\n\t"
         "s_branch 99f\n"
         // ---- match: is-simple [state] ----
         "20:\n\t"
@@ -397,10 +444,9 @@ __device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code,
         "s_add_u32 %[r0], %[r0], %[x]\n"
         "30:\n\t"
         "s_cmp_eq_u32 %[r0], -1\n\t"                     // an end marker is illegal in LZMA2 (lzma.lisp:727-732)
-        "s_cmov_b32 %[bad], 1\n\t"
+        "s_cmov_b32 %[bad], 2\n\t"
         "s_add_u32 %[val], %[val], 2\n\t"
-        "s_mov_b32 %[kind], 2\n\t"
-        "s_branch 99f\n"
+        "s_branch 60f\n"
         // ---- rep matches: uses-rep0 [12 + state] ----
         "40:\n\t"
         "s_add_u32 m0, %[st], 12\n\t"
@@ -413,8 +459,7 @@ __device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code,
         "s_cmp_lt_u32 %[st], 7\n\t"
         "s_cselect_b32 %[st], 9, 11\n\t"
         "s_mov_b32 %[val], 1\n\t"
-        "s_mov_b32 %[kind], 2\n\t"
-        "s_branch 99f\n"
+        "s_branch 60f\n"
         "44:\n\t"
         "s_add_u32 m0, %[st], 24\n\t"
         A_FLAG("%[vC]")                                  // is-rep1 [24 + state]
@@ -442,16 +487,95 @@ __device__ __forceinline__ Symbol decode_symbol(uint32_t &range, uint32_t &code,
         "s_cmp_lt_u32 %[st], 7\n\t"
         "s_cselect_b32 %[st], 8, 11\n\t"
         A_LENGTH("%[vR0]", "%[vR1]", "512", "41", "42", "43")
-        "s_add_u32 %[val], %[val], 2\n\t"
-        "s_mov_b32 %[kind], 2\n"
+        "s_add_u32 %[val], %[val], 2\n"
+        // ---- handle-match (lzma.lisp:600-612): length in val, distance - 1 in rep0 ----
+        "60:\n\t"
+        "s_cmp_ge_u32 %[r0], %[dsz]\n\t"
+        "s_cmov_b32 %[bad], 3\n\t"
+        "s_sub_u32 %[x], %[pp], %[dbase]\n\t"
+        "s_cmp_ge_u32 %[r0], %[x]\n\t"
+        "s_cmov_b32 %[bad], 4\n\t"
+        "s_sub_u32 %[x], %[endp], %[pp]\n\t"
+        "s_cmp_gt_u32 %[val], %[x]\n\t"
+        "s_cmov_b32 %[bad], 5\n\t"
+        "s_mov_b32 %[kind], 2\n\t"
+        "s_cmp_lg_u32 %[bad], 0\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        // The copy is done right here when it is the common kind: fewer than 64 bytes whose source reaches behind
+        // the ring (see the kernel: asked for from HBM, not waited for).  A ring that is due for a flush, a source
+        // inside the ring (source + 3823 > p + length) and longer matches go back to the C++ code as kind 2.
+        "s_sub_u32 %[x], %[pp], %[fl]\n\t"
+        "s_cmp_ge_u32 %[x], 0x410\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_add_u32 %[x], %[r0], %[val]\n\t"
+        "s_cmp_lt_u32 %[x], 3822\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_cmp_gt_u32 %[val], 63\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        // (a literal subtree asked for at the top of the symbol may still be on its way into v0..v3)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        // the bytes of the match before this one, if they are still on their way, go into the ring first
+        "s_cmp_eq_u32 %[plen], 0\n\t"
+        "s_cbranch_scc1 61f\n\t"
+        "v_lshlrev_b32_e32 %[tv], 2, %[lane]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "ds_read_b32 %[v0], %[tv] offset:%[stageb]\n\t"
+        "s_add_u32 %[x], %[ppend], %[shift]\n\t"
+        "v_add_u32_e32 %[tv], %[x], %[lane]\n\t"
+        "v_and_b32_e32 %[tv], 0xfff, %[tv]\n\t"
+        "v_cmp_gt_u32_e32 vcc, 32, %[psh]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_lshrrev_b32_e32 %[v0], %[psh], %[v0]\n\t"
+        "v_cndmask_b32_e32 %[v0], %[pl], %[v0], vcc\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[plen], %[lane]\n\t"
+        "s_and_saveexec_b64 %[mq], vcc\n\t"
+        "ds_write_b8 %[tv], %[v0]\n\t"
+        "s_mov_b64 exec, %[mq]\n\t"
+        "s_mov_b32 %[plen], 0\n"
+        "61:\n\t"
+        // lane k <= length takes source byte k (lane `length`: the byte behind the source, what a literal right
+        // behind the match is matched against); bytes the ring still holds are taken from there
+        "s_sub_u32 %[x], %[pp], %[r0]\n\t"
+        "s_sub_u32 %[x], %[x], 1\n\t"
+        "v_cmp_ge_u32_e32 vcc, %[val], %[lane]\n\t"
+        "v_cndmask_b32_e32 %[tv], 0, %[lane], vcc\n\t"
+        "v_add_u32_e32 %[tv], %[x], %[tv]\n\t"           // source position of this lane
+        "v_add_u32_e32 %[v1], %[obl], %[tv]\n\t"
+        "v_add_u32_e32 %[v3], 0xeef, %[tv]\n\t"
+        "v_and_b32_e32 %[v2], 3, %[v1]\n\t"
+        "v_cmp_ge_u32_e32 vcc, %[pp], %[v3]\n\t"         // in HBM only: position + 3823 <= p
+        "v_lshlrev_b32_e32 %[v2], 3, %[v2]\n\t"
+        "v_and_b32_e32 %[v1], -4, %[v1]\n\t"
+        "v_cndmask_b32_e32 %[psh], 32, %[v2], vcc\n\t"
+        "v_cndmask_b32_e32 %[v1], 0, %[v1], vcc\n\t"
+        "v_add_u32_e32 %[tv], %[shift], %[tv]\n\t"
+        "v_and_b32_e32 %[tv], 0xfff, %[tv]\n\t"
+        "ds_read_u8 %[pl], %[tv]\n\t"
+        "s_mov_b32 m0, %[stageb]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %[v1], %[ob4] sc1\n\t"
+        "s_mov_b32 %[plen], %[val]\n\t"
+        "s_mov_b32 %[ppend], %[pp]\n\t"
+        "s_add_u32 %[pp], %[pp], %[val]\n\t"
+        "s_add_u32 %[tot], %[tot], %[val]\n\t"
+        "s_mov_b32 %[kind], 3\n\t"
+        "s_cmp_eq_u32 %[pp], %[endp]\n\t"
+        "s_cbranch_scc1 99f\n\t"
+        "s_cmp_lt_u32 %[off], 192\n\t"
+        "s_cbranch_scc1 5b\n"
         "99:\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
         : [vA] "+v"(vA), [vB] "+v"(vB), [vC] "+v"(vC), [vS0] "+v"(vS0), [vS1] "+v"(vS1), [vR0] "+v"(vR0), [vR1] "+v"(vR1),
           [st] "+s"(state), [r0] "+s"(rep0), [r1] "+s"(rep1), [r2] "+s"(rep2), [r3] "+s"(rep3), A_RC_OUT, [mb] "=&s"(mb),
           [kind] "=&s"(kind), [val] "=&s"(val), [bad] "=&s"(bad), [f] "=&s"(f), [x] "=&s"(x), [y] "=&s"(y), [base] "=&s"(base),
           [q] "=&s"(q), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [tv] "=&v"(tv)
-        : [win] "v"(win), [ps] "s"(ps), [la] "v"(lit_addr), [l2] "v"(lane2), [slotb] "i"(slotb), [midb] "i"(midb),
-          [highb] "i"(highb)
-        : "scc", "m0", "memory");
+          , [pp] "+s"(r.p), [tot] "+s"(r.total), [prev] "+s"(r.prev), [ps] "=&s"(ps), [la] "=&v"(la),
+          [plen] "+s"(r.pend_len), [ppend] "+s"(r.pend_p), [psh] "+v"(r.pend_sh), [pl] "+v"(r.pend_l)
+        : [win] "v"(win), [l2] "v"(lane2), [slotb] "i"(slotb), [midb] "i"(midb), [highb] "i"(highb), [litb] "i"(litb),
+          [endp] "s"(r.endp), [fl] "s"(r.flushed), [shift] "s"(r.shift), [lc] "s"(r.lc), [lc8] "s"(r.lc8), [lpm] "s"(r.lp_mask),
+          [pbm] "s"(r.pb_mask), [dsz] "s"(r.dict_size), [dbase] "s"(r.dict_base), [obl] "s"(r.ob_low), [ob4] "s"(r.ob4),
+          [lane] "v"(lane), [stageb] "i"(stageb)
+        : "scc", "vcc", "m0", "memory");
     return Symbol{kind, val, bad};
 }
 
@@ -622,6 +746,8 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     // (byte addresses in LDS of the trees decode_symbol reads and writes)
     constexpr uint32_t lit_lds = __builtin_offsetof(FastLds, lit);
     const uint32_t lane2 = 2 * lane;
+    const uint32_t ob_low = (uint32_t)((uintptr_t)ob & 3);
+    const uint64_t ob4 = (uint64_t)(uintptr_t)ob - ob_low;
     if (uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.ring) != 0) { retry(); return; }   // (see decode_symbol)
     auto resolve = [&]() -> uint32_t {                    // returns the bytes, one per lane
         LZ_STAMP(7);
@@ -723,18 +849,39 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
         while (p != endp) {
             PIN_ALL();
             s.slide();
-            const uint32_t ps = total & pb_mask;
-            // (after a literal: the address of this context's literal subtree, lane by lane; decode_symbol reads it)
-            uint32_t lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
+            Run run{p, total, prev, endp, flushed, shift, lc, 8 - lc, lp_mask, pb_mask, dict_size, dict_base, ob_low, ob4,
+                    pend_len, pend_p, pend_sh, pend_l};
             LZ_STAMP(7);
-            const Symbol sym = decode_symbol(range, code, s.off, s.v, state, rep0, rep1, rep2, rep3, ps, vA, vB, vC, vS0, vS1, vR0,
-                                             vR1, lit_lds + 2 * lbase + lane2, lane2);
+            const Symbol sym = decode_symbols(range, code, s.off, s.v, state, rep0, rep1, rep2, rep3, run, vA, vB, vC, vS0, vS1, vR0,
+                                              vR1, lane2, lane);
+            p = run.p; total = run.total; prev = run.prev;
+            pend_len = run.pend_len; pend_p = run.pend_p; pend_sh = run.pend_sh; pend_l = run.pend_l;
             LZ_STAMP(0);
             LZ_COUNT(sym.kind);
-            if (sym.bad) { ok = false; break; }
-            if (sym.kind < 2) {
-                uint32_t byte = sym.val;
-                if (sym.kind == 1) {
+            if (sym.bad) { ok = false; WHY(sym.bad); break; }
+            if (sym.kind == 0 || sym.kind == 3) {
+                // a run of literals and far matches, applied already; it ended at the chunk's end, for a flush or for
+                // the input window
+                if (s.pos() > chunk_end) { ok = false; WHY(2); break; }
+                if (p - flushed >= (uint32_t)F_FLUSH + 16) {
+                    if (pend_len) {                  // (a literal may follow: it needs the match's last byte and match byte)
+                        const uint32_t n = uni(pend_len);
+                        const uint32_t bv = resolve();
+                        prev_v = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)(n - 1)) & 0xFF;
+                        mbyte_v = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)n) & 0xFF;
+                    }
+                    lds_sync();
+                    LZ_STAMP(2);
+                    flush(false);
+                    LZ_STAMP(3);
+                }
+                LZ_STAMP(2);
+                continue;
+            }
+            if (sym.kind == 1) {
+                uint32_t byte = 0;
+                uint32_t lbase;
+                {
                     // ---- a literal behind a match (lzma.lisp:497-518): walk the match byte's path while the bits agree ----
                     uint32_t mb;
                     if (pend_len) {
@@ -791,9 +938,9 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
             }
             // ---- match ----
             const uint32_t len = sym.val;
-            if (!ok || s.pos() > chunk_end) { ok = false; break; }
+            if (!ok || s.pos() > chunk_end) { ok = false; WHY(3); break; }
             // handle-match, lzma.lisp:600-612
-            if (rep0 >= dict_size || rep0 >= p - dict_base || len > endp - p) { ok = false; break; }
+            if (rep0 >= dict_size || rep0 >= p - dict_base || len > endp - p) { ok = false; WHY(4); break; }
             // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
             if (pend_len) resolve();
             if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); LZ_STAMP(4); flush(false); LZ_STAMP(3); }
@@ -866,7 +1013,7 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
         total &= 15;
         // eof-mode :never at the declared size (lzma.lisp:644-647): the range decoder must be able to finish;
         // and the chunk must have used exactly its compressed size (lzma2.lisp:200-201)
-        if (code != 0 || s.pos() != chunk_end) { ok = false; break; }
+        if (code != 0 || s.pos() != chunk_end) { ok = false; WHY(5); break; }
     }
 #undef BIT
     if (!ok) { retry(); return; }

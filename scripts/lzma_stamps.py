@@ -24,3 +24,6 @@ for i, n in enumerate(names):
 lit, mlit, match, far, _slow = (st[8 + i] / units for i in range(5))
 print(f"per unit: literals {lit:.0f} literals behind a match {mlit:.0f} matches {match:.0f} of them far (deferred) {far:.0f} long far {_slow:.0f}")
 print(f"ticks per symbol: {tot / units / max(1, lit + mlit + match):.0f}; decode_symbol alone {st[0] / units / max(1, lit + mlit + match):.0f}")
+why = st[15]
+print("units handed to the general kernel, by reason (1 direct bits, 2 end marker, 3 dict size, 4 no data, 5 beyond the chunk):",
+      [(why >> (8 * i)) & 0xFF for i in range(1, 6)], "(counts modulo 256)")
