@@ -260,6 +260,10 @@ __device__ __forceinline__ uint32_t ld_bytes_le(const uint8_t *p, int n)
 enum { EOF_MAYBE = 0, EOF_ALWAYS = 1, EOF_NEVER = 2 };          // eof-mode, lzma.lisp:575-577
 constexpr uint32_t WIDE_LIT_PROBS = 0x300u << 12;               // lc <= 8, lp <= 4 (lzma.lisp:818-819)
 
+// Units the accept-only kernel of lzma2_fast.hip handed to this one, since the library was loaded (option
+// "lzma-handed-back": tests make sure that well-formed blocks never take the slow road).
+__device__ unsigned g_lz_handed_back;
+
 // WIDE: the literal coder's probabilities live in `wide` (WIDE_LIT_PROBS entries per unit) instead of LDS
 // SMALL: see LzSize; retry_pass: only the units that the small kernel left with LZ_RETRY_FULL are decoded
 template <bool WIDE, bool SMALL>
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(64, 1) void lzma2_kernel(const uint8_t *in, uint64_
     const uint32_t u = blockIdx.x;
     if (u >= nunits) return;
     if (retry_pass && uni(__hip_atomic_load(&results[u].status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != LZ_RETRY_FULL) return;
+    if (SMALL && retry_pass == 2 && lane == 0) atomicAdd(&g_lz_handed_back, 1u);
     semz_unit un;
     {
         k_u32p up = (k_u32p)(uintptr_t)(units + u);
@@ -857,6 +862,14 @@ __global__ __launch_bounds__(256) void bcj_simple_kernel(const semz_unit *units,
 
 } // namespace
 
+int semz_lzma2_handed_back(long *value)
+{
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_lz_handed_back), sizeof v) != hipSuccess) return -1;
+    *value = (long)v;
+    return 0;
+}
+
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide)
 {
@@ -877,7 +890,7 @@ int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_u
             semz_span_end(c);
         }
         semz_span_begin(c, "lzma2_kernel");
-        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, c->lz_no_fast ? 0 : 1);
+        lzma2_kernel<false, true><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, c->lz_no_fast ? 0 : 2);
         lzma2_kernel<false, false><<<nunits, 64, 0, c->stream>>>(d_in, in_len, d_units, nunits, d_out, out_cap, d_results, d_tails, nullptr, 1);
         semz_span_end(c);
     }

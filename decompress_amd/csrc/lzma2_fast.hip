@@ -11,11 +11,11 @@
 // What bounds an LZMA decoder on this chip is the number of instructions per decoded bit: a
 // wave issues one instruction every eight clocks or so whatever its kind, and a
 // batch of 1 MiB blocks has two waves per SIMD at most.  The general kernel spends about 47
-// instructions per bit; this one spends about 17:
+// instructions per bit; this one spends about 15, and next to nothing between the bits:
 //
 //  * Probabilities live in vector registers, one model per lane, and a bit step takes its
-//    probability with v_readlane and puts it back with v_writelane: no LDS round trip, no
-//    address arithmetic.  The flag models, the length decoders' low / mid trees and the align
+//    probability with v_readlane and updates it in place (all lanes computed, one lane kept):
+//    no LDS round trip, no address arithmetic.  The flag models, the length decoders' low / mid trees and the align
 //    tree stay in registers for the whole unit; the 0x300-entry literal subtree of the current
 //    context, the distance-slot tree, the distance trees of slots 4..13 and the length
 //    decoders' high trees are fetched from LDS into registers when a symbol needs them (the
@@ -122,121 +122,29 @@ __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); 
                  [nc] "=&s"(nc), [k] "=&s"(k), [mq] "=&s"(mq), [t] "=&v"(t)
 #define A_TEMPS uint32_t p, b, nr, nc, k, t; uint64_t mq
 
-// One modelled bit with the model in lane `sel` of vt; returns q' = 2 q + (bit == 0).
-__device__ __forceinline__ uint32_t bitq(uint32_t &vt, uint32_t sel, uint32_t &range, uint32_t &code, uint32_t &off,
-                                         uint32_t win, uint32_t q)
-{
-    A_TEMPS;
-    asm volatile("s_mov_b32 m0, %[sel]\n\t" A_BIT_HEAD("%[vt]") "s_addc_u32 %[q], %[q], %[q]\n\t" A_BIT_TAIL("%[vt]") A_NORM
-                 : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT
-                 : [sel] "s"(sel), [win] "v"(win)
-                 : "scc", "m0");
-    return q;
-}
-
-// N levels of a tree whose models sit in lanes q of one register (N <= 6).
-template <int N> __device__ __forceinline__ uint32_t walk(uint32_t &vt, uint32_t &range, uint32_t &code, uint32_t &off,
-                                                           uint32_t win, uint32_t q)
-{
-    A_TEMPS;
-    static_assert(N >= 1 && N <= 6, "one register holds the first six levels");
-#define A_WALK(body) asm volatile("s_mov_b32 m0, %[q]\n\t" body "s_mov_b32 %[q], m0" \
-                                  : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [win] "v"(win) : "scc", "m0")
-    if constexpr (N == 6) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
-    else if constexpr (N == 5) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
-    else if constexpr (N == 4) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
-    else if constexpr (N == 3) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]") A_TREE("%[vt]"));
-    else if constexpr (N == 2) A_WALK(A_TREE("%[vt]") A_TREE("%[vt]"));
-    else A_WALK(A_TREE("%[vt]"));
-#undef A_WALK
-    return q;
-}
-
-// Three or four levels of a small tree with its models in lanes base + q.
-template <int N> __device__ __forceinline__ uint32_t walkb(uint32_t &vt, uint32_t base, uint32_t &range, uint32_t &code,
-                                                            uint32_t &off, uint32_t win)
-{
-    A_TEMPS;
-    uint32_t q = 1;
-    static_assert(N == 3 || N == 4, "length low / mid trees and the align tree");
-    if constexpr (N == 3)
-        asm volatile(A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]")
-                     : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [base] "s"(base), [win] "v"(win) : "scc", "m0");
-    else
-        asm volatile(A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]") A_TREEB("%[vt]")
-                     : [vt] "+v"(vt), [q] "+s"(q), A_RC_OUT : [base] "s"(base), [win] "v"(win) : "scc", "m0");
-    return q;
-}
-
-// An eight-level tree in four registers (levels 0..5, 6, and 7 in two halves); returns q in 256..511.
-__device__ __forceinline__ uint32_t tree8(uint32_t &v0, uint32_t &v1, uint32_t &v2, uint32_t &v3, uint32_t &range,
-                                          uint32_t &code, uint32_t &off, uint32_t win)
-{
-    A_TEMPS;
-    uint64_t mb;
-    uint32_t q;
-    asm volatile("s_mov_b32 m0, 1\n\t"
-                 A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]") A_TREE("%[v0]")
-                 A_TREE("%[v1]") A_LEVEL7("%[v2]", "%[v3]")
-                 "s_mov_b32 %[q], m0"
-                 : [v0] "+v"(v0), [v1] "+v"(v1), [v2] "+v"(v2), [v3] "+v"(v3), [q] "=&s"(q), A_RC_OUT, [mb] "=&s"(mb)
-                 : [win] "v"(win)
-                 : "scc", "m0");
-    return q;
-}
-
-// The last level alone (a matched literal that left the match byte's path at level 7 or finished it there).
-__device__ __forceinline__ uint32_t level7(uint32_t &v2, uint32_t &v3, uint32_t &range, uint32_t &code, uint32_t &off,
-                                           uint32_t win, uint32_t q)
-{
-    A_TEMPS;
-    uint64_t mb;
-    asm volatile("s_mov_b32 m0, %[q]\n\t" A_LEVEL7("%[v2]", "%[v3]") "s_mov_b32 %[q], m0"
-                 : [v2] "+v"(v2), [v3] "+v"(v3), [q] "+s"(q), A_RC_OUT, [mb] "=&s"(mb)
-                 : [win] "v"(win)
-                 : "scc", "m0");
-    return q;
-}
-
-// `n` >= 1 direct bits (lzma.lisp:174-192): the range is halved, hi' = 2 hi + (bit == 0).  `bad` is set when the
-// code equals the halved range after a one bit, the reference's only failure here.
-__device__ __forceinline__ uint32_t direct_bits(uint32_t n, uint32_t &range, uint32_t &code, uint32_t &off, uint32_t win,
-                                                uint32_t &bad)
-{
-    uint32_t b, k, hi = 0, m = 1u << (n - 1);
-    asm volatile("2:\n\t"
-                 "s_lshr_b32 %[range], %[range], 1\n\t"
-                 "s_sub_u32 %[b], %[code], %[range]\n\t"        /* SCC = code < range: the bit is 0 */
-                 "s_cselect_b32 %[code], %[code], %[b]\n\t"
-                 "s_addc_u32 %[hi], %[hi], %[hi]\n\t"
-                 "s_cmp_eq_u32 %[code], %[range]\n\t"
-                 "s_cmov_b32 %[bad], 1\n\t" A_NORM
-                 "s_lshr_b32 %[m], %[m], 1\n\t"                 /* SCC = result != 0 */
-                 "s_cbranch_scc1 2b"
-                 : [range] "+s"(range), [code] "+s"(code), [off] "+s"(off), [hi] "+s"(hi), [m] "+s"(m), [bad] "+s"(bad),
-                   [b] "=&s"(b), [k] "=&s"(k)
-                 : [win] "v"(win)
-                 : "scc");
-    return hi;
-}
-
-// ---- one LZMA symbol, decoded by ONE block of assembler ----
+// ---- runs of LZMA symbols, decoded and applied by ONE block of assembler ----
 // Between the bit runs above the compiler used to write the symbol's state machine: which flag comes next, which
 // tree, the rep rotation, the state update.  With the models as read-write operands of many small blocks under C++
 // control flow that was copies of model registers around every join, booleans kept as lane masks and spilled, and
-// about 150 instructions of glue per symbol (33 M of a 1 MiB block's 84 M).  The whole decision tree of a symbol
-// (lzma.lisp:566-775 without the LZ copies) is now straight assembler: is-literal; the literal's eight-level tree
-// (after a literal: its context's subtree is read from LDS at the top and written back at the end); is-simple,
-// the length decoders with their high trees in LDS, the slot tree, the reverse trees of slots 4..13, the direct
-// bits and the align tree; the rep flags with the rotation of rep0..rep3; the state table (lzma.lisp:615).  What
-// Literals that follow a literal are applied right here (ring, position, context of the next symbol) and the next
-// symbol is taken up at once, as long as the chunk goes on, the ring is not due for a flush and the input window
-// does not have to move.  What
-// comes out: kind 0 = the run ended behind a literal for one of those reasons, 1 = a literal that follows a match (only its flag is decoded: the
-// matched walk needs the match byte, which may still be on its way from HBM, so the C++ code below takes over),
-// 2 = match (val = length; rep0 and state are updated).  `bad` = the one failure of the direct bits
-// (lzma.lisp:186-188) or an end marker; the caller hands the unit to the general kernel.
-// Labels: 1 belongs to A_NORM; 10..99 are this block's.
+// about 150 instructions of glue per symbol; and every return to the C++ loop cost another 170 or so (scalar state
+// written to and read from lanes of a spill register).  The whole of decode-lzma (lzma.lisp:566-775) for the common
+// symbols is now straight assembler that loops from symbol to symbol:
+//  * the decision tree: is-literal; the literal's eight-level tree (after a literal: its context's subtree is read
+//    from LDS at the top and written back at the end); is-simple, the length decoders with their high trees in LDS,
+//    the slot tree, the reverse trees of slots 4..13, the direct bits and the align tree; the rep flags with the
+//    rotation of rep0..rep3; the state table (lzma.lisp:615);
+//  * a literal behind a match (lzma.lisp:497-518): the eight models on the match byte's path sit in lanes 0..7 of
+//    one register (one LDS read), the walk follows them while the decoded bits agree with the match byte and goes
+//    on in the plain tree from the level where they part;
+//  * literals are applied (ring, position, context of the next symbol);
+//  * matches shorter than 64 bytes whose distance is at least their length are applied without waiting for their
+//    bytes: lane k asks for source byte k (ring: ds_read; older than the ring: the dword around it, HBM -> LDS
+//    stage, see the kernel), and the bytes go into the ring when the next symbol needs them (A_RESOLVE).
+// The block returns when the chunk's output is complete, the ring is due for a flush, the input window has to move
+// (kind 0 behind a literal, 3 behind a match), or for a match it does not apply (kind 2, val = length; rep0 and
+// state are updated, handle-match's checks lzma.lisp:600-612 are done).  `bad` != 0: one of those checks, the one
+// failure of the direct bits (lzma.lisp:186-188) or an end marker; the caller hands the unit to the general kernel.
+// Labels: 1 belongs to A_NORM; 5..99 are this block's.
 #define A_FLAG(vt) A_BIT_HEAD(vt) "s_cselect_b32 %[f], 1, 0\n\t" A_BIT_TAIL(vt) A_NORM "s_cmp_eq_u32 %[f], 0\n\t"
 #define A_TREE6(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt) A_TREE(vt)
 #define A_LDS_TREE8_IN(addr) "ds_read_u16 %[v0], " addr "\n\tds_read_u16 %[v1], " addr " offset:128\n\t" \
@@ -244,6 +152,22 @@ __device__ __forceinline__ uint32_t direct_bits(uint32_t n, uint32_t &range, uin
 #define A_LDS_TREE8_OUT(addr) "ds_write_b16 " addr ", %[v0]\n\tds_write_b16 " addr ", %[v1] offset:128\n\t" \
                               "ds_write_b16 " addr ", %[v2] offset:256\n\tds_write_b16 " addr ", %[v3] offset:384\n\t"
 #define A_TREE8 "s_mov_b32 m0, 1\n\t" A_TREE6("%[v0]") A_TREE("%[v1]") A_LEVEL7("%[v2]", "%[v3]")
+// The bytes of the match that is still on its way (see the kernel) go into the ring; v0 = the bytes, one per lane.
+#define A_RESOLVE                                                                                                   \
+    "v_lshlrev_b32_e32 %[tv], 2, %[lane]\n\t"                                                                       \
+    "s_waitcnt vmcnt(0)\n\t"                                                                                        \
+    "ds_read_b32 %[v0], %[tv] offset:%[stageb]\n\t"                                                                 \
+    "s_add_u32 %[x], %[ppend], %[shift]\n\t"                                                                        \
+    "v_add_u32_e32 %[tv], %[x], %[lane]\n\t"                                                                        \
+    "v_and_b32_e32 %[tv], 0xfff, %[tv]\n\t"                                                                         \
+    "v_cmp_gt_u32_e32 vcc, 32, %[psh]\n\t"                                                                          \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                                      \
+    "v_lshrrev_b32_e32 %[v0], %[psh], %[v0]\n\t"                                                                    \
+    "v_cndmask_b32_e32 %[v0], %[pl], %[v0], vcc\n\t"                                                                \
+    "v_cmp_gt_u32_e32 vcc, %[plen], %[lane]\n\t"                                                                    \
+    "s_and_saveexec_b64 %[mq], vcc\n\t"                                                                             \
+    "ds_write_b8 %[tv], %[v0]\n\t"                                                                                  \
+    "s_mov_b64 exec, %[mq]\n\t"
 // decode-lzma-length (lzma.lisp:247-257): low tree and the two choices in w0, mid tree in w1, high tree in LDS at
 // %[highb] + hoff; leaves the length code 0..271 in %[val].  la / lb / lc: three labels of this expansion.
 #define A_LENGTH(w0, w1, hoff, la, lb, lc)                                                                          \
@@ -285,7 +209,8 @@ struct Symbol { uint32_t kind, val, bad; };
 
 // Position state of a run of symbols (decode_symbols): where the output stands and what ends the run.
 struct Run {
-    uint32_t p, total, prev;       // output position, total-i-mod-16 counter (not reduced here), last byte (valid after a literal)
+    uint32_t p, total;             // output position, total-i-mod-16 counter (not reduced here)
+    uint32_t prev, mbyte;          // last byte; behind a match: the byte that follows the match's source (both only if pend_len == 0)
     uint32_t endp, flushed;        // end of the chunk's output; bytes of the ring that are in HBM already
     uint32_t shift;                // ring index of output position 0
     uint32_t lc, lc8, lp_mask, pb_mask;   // lc, 8 - lc, masks of lp and pb
@@ -309,7 +234,7 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
     uint32_t ps, la;
     A_TEMPS;
     uint64_t mb;
-    uint32_t kind, val, bad, f, x, y, base, q, v0, v1, v2, v3, tv;
+    uint32_t kind, val, bad, f, x, y, base, q, v0, v1, v2, v3, tv, vm;
     asm volatile(
         "s_mov_b32 %[bad], 0\n"
         // ---- top of a symbol: pos_state, and (after a literal) the address of the context's literal subtree ----
@@ -332,16 +257,16 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         A_FLAG("%[vA]")
         "s_cbranch_scc1 20f\n\t"
         // ---- literal (lzma.lisp:661-688) ----
-        "s_mov_b32 %[kind], 1\n\t"
         "s_cmp_gt_u32 %[st], 6\n\t"
-        "s_cbranch_scc1 99f\n\t"
+        "s_cbranch_scc1 70f\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
         A_TREE8
         A_LDS_TREE8_OUT("%[la]")
         "s_andn2_b32 %[prev], 0xff, m0\n\t"              // the byte
         "s_sub_u32 %[x], %[st], 3\n\t"
         "s_cmp_lt_u32 %[st], 4\n\t"
-        "s_cselect_b32 %[st], 0, %[x]\n\t"
+        "s_cselect_b32 %[st], 0, %[x]\n"
+        "15:\n\t"
         // the literal goes into the ring (every lane: same address, same value) and the next symbol follows at once
         // unless the chunk is complete, the ring is due for a flush or the input window has to move
         "s_add_u32 %[x], %[pp], %[shift]\n\t"
@@ -360,6 +285,83 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         "s_cmp_lt_u32 %[off], 192\n\t"
         "s_cbranch_scc1 5b\n\t"
         "s_branch 99f\n"
+        // ---- a literal behind a match (lzma.lisp:497-518): the match byte's path is walked while the bits agree ----
+        "70:\n\t"
+        // the byte in front and the match byte: lanes length - 1 and length of a match whose bytes are still on their way
+        "s_cmp_eq_u32 %[plen], 0\n\t"
+        "s_cbranch_scc1 71f\n\t"
+        A_RESOLVE
+        "s_sub_u32 %[x], %[plen], 1\n\t"
+        "v_readlane_b32 %[mbyte], %[v0], %[plen]\n\t"
+        "v_readlane_b32 %[prev], %[v0], %[x]\n\t"
+        "s_mov_b32 %[plen], 0\n\t"
+        "s_and_b32 %[mbyte], %[mbyte], 0xff\n\t"
+        "s_and_b32 %[prev], %[prev], 0xff\n"
+        "71:\n\t"
+        "s_and_b32 %[x], %[tot], %[lpm]\n\t"
+        "s_lshr_b32 %[y], %[prev], %[lc8]\n\t"
+        "s_lshl_b32 %[x], %[x], %[lc]\n\t"
+        "s_or_b32 %[x], %[x], %[y]\n\t"
+        "s_mulk_i32 %[x], 0x600\n\t"
+        "s_add_u32 %[x], %[x], %[litb]\n\t"
+        "v_add_u32_e32 %[la], %[x], %[l2]\n\t"
+        A_LDS_TREE8_IN("%[la]")
+        // lane l < 8: the model of level l on the match byte's path, [0x100 + (match bit << 8) + q] with the path's q,
+        // which is the top of I = 0x100 | ~match byte (q counts zero bits as ones here)
+        "s_andn2_b32 %[y], 0xff, %[mbyte]\n\t"
+        "v_and_b32_e32 %[vm], 7, %[lane]\n\t"
+        "s_or_b32 %[y], %[y], 0x100\n\t"
+        "v_sub_u32_e32 %[vm], 8, %[vm]\n\t"
+        "s_lshl_b32 %[f], %[mbyte], 1\n\t"
+        "v_lshrrev_b32_e64 %[tv], %[vm], %[y]\n\t"
+        "v_lshrrev_b32_e64 %[t], %[vm], %[f]\n\t"
+        "s_add_u32 %[x], %[x], 0x200\n\t"
+        "v_and_b32_e32 %[t], 1, %[t]\n\t"
+        "v_lshl_add_u32 %[tv], %[t], 8, %[tv]\n\t"
+        "v_lshl_add_u32 %[tv], %[tv], 1, %[x]\n\t"
+        "ds_read_u16 %[vm], %[tv]\n\t"
+        "s_mov_b32 %[q], 1\n\t"
+        "s_mov_b32 %[x], 7\n\t"
+        "s_mov_b32 m0, 0\n\t"
+        "s_waitcnt lgkmcnt(0)\n"
+        "72:\n\t"
+        A_BIT_HEAD("%[vm]") "s_addc_u32 %[q], %[q], %[q]\n\t" A_BIT_TAIL("%[vm]") A_NORM
+        "s_lshr_b32 %[f], %[y], %[x]\n\t"              // q of the path behind this level
+        "s_add_u32 m0, m0, 1\n\t"
+        "s_sub_u32 %[x], %[x], 1\n\t"
+        "s_cmp_lg_u32 %[q], %[f]\n\t"
+        "s_cbranch_scc1 73f\n\t"
+        "s_cmp_lt_u32 m0, 8\n\t"
+        "s_cbranch_scc1 72b\n"
+        "73:\n\t"
+        "s_mov_b64 exec, 0xff\n\t"
+        "ds_write_b16 %[tv], %[vm]\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        // the plain tree from the level the walk has reached (m0) on: levels 0..5 in v0, 6 in v1, 7 in v2 / v3
+        "s_mov_b32 %[x], m0\n\t"
+        "s_mov_b32 m0, %[q]\n\t"
+        "s_cmp_gt_u32 %[x], 7\n\t"
+        "s_cbranch_scc1 77f\n"
+        "74:\n\t"
+        "s_cmp_gt_u32 %[x], 5\n\t"
+        "s_cbranch_scc1 75f\n\t"
+        A_TREE("%[v0]")
+        "s_add_u32 %[x], %[x], 1\n\t"
+        "s_branch 74b\n"
+        "75:\n\t"
+        "s_cmp_gt_u32 %[x], 6\n\t"
+        "s_cbranch_scc1 76f\n\t"
+        A_TREE("%[v1]")
+        "76:\n\t"
+        A_LEVEL7("%[v2]", "%[v3]")
+        A_LDS_TREE8_OUT("%[la]")
+        "77:\n\t"
+        "s_andn2_b32 %[prev], 0xff, m0\n\t"              // the byte
+        "s_sub_u32 %[x], %[st], 3\n\t"
+        "s_sub_u32 %[y], %[st], 6\n\t"
+        "s_cmp_lt_u32 %[st], 10\n\t"
+        "s_cselect_b32 %[st], %[x], %[y]\n\t"            // lzma.lisp:615 (state >= 7 here)
+        "s_branch 15b\n"
         // ---- match: is-simple [state] ----
         "20:\n\t"
         "s_mov_b32 m0, %[st]\n\t"
@@ -507,8 +509,7 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         "s_sub_u32 %[x], %[pp], %[fl]\n\t"
         "s_cmp_ge_u32 %[x], 0x410\n\t"
         "s_cbranch_scc1 99f\n\t"
-        "s_add_u32 %[x], %[r0], %[val]\n\t"
-        "s_cmp_lt_u32 %[x], 3822\n\t"
+        "s_cmp_lt_u32 %[r0], %[val]\n\t"
         "s_cbranch_scc1 99f\n\t"
         "s_cmp_gt_u32 %[val], 63\n\t"
         "s_cbranch_scc1 99f\n\t"
@@ -517,20 +518,7 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         // the bytes of the match before this one, if they are still on their way, go into the ring first
         "s_cmp_eq_u32 %[plen], 0\n\t"
         "s_cbranch_scc1 61f\n\t"
-        "v_lshlrev_b32_e32 %[tv], 2, %[lane]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "ds_read_b32 %[v0], %[tv] offset:%[stageb]\n\t"
-        "s_add_u32 %[x], %[ppend], %[shift]\n\t"
-        "v_add_u32_e32 %[tv], %[x], %[lane]\n\t"
-        "v_and_b32_e32 %[tv], 0xfff, %[tv]\n\t"
-        "v_cmp_gt_u32_e32 vcc, 32, %[psh]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_lshrrev_b32_e32 %[v0], %[psh], %[v0]\n\t"
-        "v_cndmask_b32_e32 %[v0], %[pl], %[v0], vcc\n\t"
-        "v_cmp_gt_u32_e32 vcc, %[plen], %[lane]\n\t"
-        "s_and_saveexec_b64 %[mq], vcc\n\t"
-        "ds_write_b8 %[tv], %[v0]\n\t"
-        "s_mov_b64 exec, %[mq]\n\t"
+        A_RESOLVE
         "s_mov_b32 %[plen], 0\n"
         "61:\n\t"
         // lane k <= length takes source byte k (lane `length`: the byte behind the source, what a literal right
@@ -551,9 +539,13 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         "v_add_u32_e32 %[tv], %[shift], %[tv]\n\t"
         "v_and_b32_e32 %[tv], 0xfff, %[tv]\n\t"
         "ds_read_u8 %[pl], %[tv]\n\t"
+        "s_add_u32 %[x], %[r0], %[val]\n\t"
+        "s_cmp_lt_u32 %[x], 3822\n\t"                  // every byte is in the ring
+        "s_cbranch_scc1 62f\n\t"
         "s_mov_b32 m0, %[stageb]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dword %[v1], %[ob4] sc1\n\t"
+        "global_load_lds_dword %[v1], %[ob4] sc1\n"
+        "62:\n\t"
         "s_mov_b32 %[plen], %[val]\n\t"
         "s_mov_b32 %[ppend], %[pp]\n\t"
         "s_add_u32 %[pp], %[pp], %[val]\n\t"
@@ -569,7 +561,7 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
           [st] "+s"(state), [r0] "+s"(rep0), [r1] "+s"(rep1), [r2] "+s"(rep2), [r3] "+s"(rep3), A_RC_OUT, [mb] "=&s"(mb),
           [kind] "=&s"(kind), [val] "=&s"(val), [bad] "=&s"(bad), [f] "=&s"(f), [x] "=&s"(x), [y] "=&s"(y), [base] "=&s"(base),
           [q] "=&s"(q), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [tv] "=&v"(tv)
-          , [pp] "+s"(r.p), [tot] "+s"(r.total), [prev] "+s"(r.prev), [ps] "=&s"(ps), [la] "=&v"(la),
+          , [pp] "+s"(r.p), [tot] "+s"(r.total), [prev] "+s"(r.prev), [ps] "=&s"(ps), [la] "=&v"(la), [vm] "=&v"(vm), [mbyte] "+s"(r.mbyte),
           [plen] "+s"(r.pend_len), [ppend] "+s"(r.pend_p), [psh] "+v"(r.pend_sh), [pl] "+v"(r.pend_l)
         : [win] "v"(win), [l2] "v"(lane2), [slotb] "i"(slotb), [midb] "i"(midb), [highb] "i"(highb), [litb] "i"(litb),
           [endp] "s"(r.endp), [fl] "s"(r.flushed), [shift] "s"(r.shift), [lc] "s"(r.lc), [lc8] "s"(r.lc8), [lpm] "s"(r.lp_mask),
@@ -734,7 +726,6 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
         p = uni(p); total = uni(total); prev = uni(prev); flushed = uni(flushed);                                       \
         dict_base = uni(dict_base); s.wbase = uni(s.wbase);                                                             \
     } while (0)
-#define BIT(vt, sel) (q = bitq(vt, sel, range, code, s.off, s.v, q))
 
     // A match whose source lies behind the ring is not waited for: its bytes are asked for (HBM, one round trip) and
     // put into the ring when something needs them -- the next literal (context and match byte), the next match's
@@ -742,13 +733,10 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
     // bits do not depend on the bytes.  Lane k < pend_len holds byte k, lane pend_len the byte behind the source
     // (what a literal right behind the match is matched against).
     uint32_t pend_len = 0, pend_p = 0, pend_sh = 0, pend_l = 0;
-    const uint32_t stage_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)L.stage;
-    // (byte addresses in LDS of the trees decode_symbol reads and writes)
-    constexpr uint32_t lit_lds = __builtin_offsetof(FastLds, lit);
     const uint32_t lane2 = 2 * lane;
     const uint32_t ob_low = (uint32_t)((uintptr_t)ob & 3);
     const uint64_t ob4 = (uint64_t)(uintptr_t)ob - ob_low;
-    if (uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.ring) != 0) { retry(); return; }   // (see decode_symbol)
+    if (uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.ring) != 0) { retry(); return; }   // (see decode_symbols)
     auto resolve = [&]() -> uint32_t {                    // returns the bytes, one per lane
         LZ_STAMP(7);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the load below is not one the compiler knows of)
@@ -837,119 +825,57 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
             lds_sync();
         }
         have_state = true;
-        // the byte in front of the chunk, for the first literal's context
+        // the byte in front of the chunk, for the first literal's context, and (behind a match) the match byte
         uint32_t prev = p == dict_base ? 0u : uni((uint32_t)L.ring[(p - 1 + shift) & F_MASK]);
-        uint32_t mbyte_v = 0, prev_v = prev;
+        uint32_t mbyte = 0;
         if (state >= 7) {
             if (p - dict_base < rep0 + 1) { ok = false; break; }
-            mbyte_v = history_byte_v(p - 1 - rep0);
+            mbyte = uni(history_byte_v(p - 1 - rep0));
         }
 
         // ---- decode-lzma (lzma.lisp:566-775) ----
         while (p != endp) {
             PIN_ALL();
             s.slide();
-            Run run{p, total, prev, endp, flushed, shift, lc, 8 - lc, lp_mask, pb_mask, dict_size, dict_base, ob_low, ob4,
+            Run run{p, total, prev, mbyte, endp, flushed, shift, lc, 8 - lc, lp_mask, pb_mask, dict_size, dict_base, ob_low, ob4,
                     pend_len, pend_p, pend_sh, pend_l};
             LZ_STAMP(7);
             const Symbol sym = decode_symbols(range, code, s.off, s.v, state, rep0, rep1, rep2, rep3, run, vA, vB, vC, vS0, vS1, vR0,
                                               vR1, lane2, lane);
-            p = run.p; total = run.total; prev = run.prev;
+            p = run.p; total = run.total; prev = run.prev; mbyte = run.mbyte;
             pend_len = run.pend_len; pend_p = run.pend_p; pend_sh = run.pend_sh; pend_l = run.pend_l;
             LZ_STAMP(0);
             LZ_COUNT(sym.kind);
             if (sym.bad) { ok = false; WHY(sym.bad); break; }
-            if (sym.kind == 0 || sym.kind == 3) {
-                // a run of literals and far matches, applied already; it ended at the chunk's end, for a flush or for
-                // the input window
-                if (s.pos() > chunk_end) { ok = false; WHY(2); break; }
-                if (p - flushed >= (uint32_t)F_FLUSH + 16) {
-                    if (pend_len) {                  // (a literal may follow: it needs the match's last byte and match byte)
-                        const uint32_t n = uni(pend_len);
-                        const uint32_t bv = resolve();
-                        prev_v = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)(n - 1)) & 0xFF;
-                        mbyte_v = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)n) & 0xFF;
-                    }
-                    lds_sync();
-                    LZ_STAMP(2);
-                    flush(false);
-                    LZ_STAMP(3);
+            if (s.pos() > chunk_end) { ok = false; WHY(2); break; }
+            // whatever ended the run, the ring may be due for a flush; the bytes of a match that are still on their
+            // way go in first (a literal may follow: it needs the match's last byte and its match byte)
+            if (p - flushed >= (uint32_t)F_FLUSH + 16) {
+                if (pend_len) {
+                    const uint32_t n = uni(pend_len);
+                    const uint32_t bv = resolve();
+                    prev = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)(n - 1)) & 0xFF;
+                    mbyte = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)n) & 0xFF;
                 }
+                lds_sync();
+                LZ_STAMP(2);
+                flush(false);
+                LZ_STAMP(3);
+            }
+            if (sym.kind != 2) {                 // a run of literals and short matches, applied already
                 LZ_STAMP(2);
                 continue;
             }
-            if (sym.kind == 1) {
-                uint32_t byte = 0;
-                uint32_t lbase;
-                {
-                    // ---- a literal behind a match (lzma.lisp:497-518): walk the match byte's path while the bits agree ----
-                    uint32_t mb;
-                    if (pend_len) {
-                        const uint32_t n = uni(pend_len);
-                        const uint32_t bv = resolve();
-                        prev = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)(n - 1)) & 0xFF;
-                        mb = (uint32_t)__builtin_amdgcn_readlane((int)bv, (int)n) & 0xFF;
-                    } else {
-                        prev = uni(prev_v);
-                        mb = uni(mbyte_v);
-                    }
-                    lbase = 0x300u * (((total & lp_mask) << lc) | (prev >> (8 - lc)));
-                    // the eight models on the match byte's path, one per lane; the other lanes take the unused slot 0
-                    const uint32_t inv = ~mb & 0xFF;
-                    const uint32_t l7 = lane & 7;
-                    const uint32_t qi = (1u << l7) | (inv >> (8 - l7));
-                    const uint32_t node = lane < 8 ? 0x100u + (((mb >> (7 - l7)) & 1) << 8) + qi : 0u;
-                    join_lanes();
-                    uint16_t *mt = L.lit + lbase + node;
-                    uint32_t vm = *mt;
-                    uint16_t *t = L.lit + lbase + lane;
-                    uint32_t v0 = t[0], v1 = t[64], v2 = t[128], v3 = t[192];
-                    uint32_t q = 1;
-                    uint32_t lvl = 0;
-                    for (; lvl < 8; lvl++) {
-                        const uint32_t want = 2 * q + (((mb >> (7 - lvl)) & 1) ^ 1);
-                        BIT(vm, lvl);
-                        if (q != want) { lvl++; break; }
-                    }
-                    *mt = (uint16_t)vm;
-                    // the plain tree from level `lvl` on: levels 0..5 sit in v0, 6 in v1, 7 in v2 / v3
-                    switch (lvl) {
-                    case 1: BIT(v0, q); [[fallthrough]];
-                    case 2: BIT(v0, q); [[fallthrough]];
-                    case 3: BIT(v0, q); [[fallthrough]];
-                    case 4: BIT(v0, q); [[fallthrough]];
-                    case 5: BIT(v0, q); [[fallthrough]];
-                    case 6: BIT(v1, q); [[fallthrough]];
-                    case 7: q = level7(v2, v3, range, code, s.off, s.v, q); break;
-                    default: break;
-                    }
-                    t[0] = (uint16_t)v0; t[64] = (uint16_t)v1; t[128] = (uint16_t)v2; t[192] = (uint16_t)v3;
-                    byte = ~q & 0xFF;
-                    state = state < 10 ? state - 3 : state - 6;          // lzma.lisp:615 (state >= 7 here)
-                }
-                if (s.pos() > chunk_end) { ok = false; break; }
-                L.ring[(p + shift) & F_MASK] = (uint8_t)byte;        // every lane: same address, same value
-                prev = byte;
-                p++;
-                total++;
-                if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); LZ_STAMP(2); flush(false); LZ_STAMP(3); }
-                LZ_STAMP(2);
-                continue;
-            }
-            // ---- match ----
+            // ---- a match the assembler block does not apply: 64 bytes or more, or closer than it is long ----
             const uint32_t len = sym.val;
-            if (!ok || s.pos() > chunk_end) { ok = false; WHY(3); break; }
-            // handle-match, lzma.lisp:600-612
-            if (rep0 >= dict_size || rep0 >= p - dict_base || len > endp - p) { ok = false; WHY(4); break; }
-            // copy-match (common.lisp:324-333), all lanes; sources older than the ring come from HBM
+            // (handle-match, lzma.lisp:600-612, was checked in decode_symbols)
             if (pend_len) resolve();
-            if (p - flushed >= (uint32_t)F_FLUSH + 16) { lds_sync(); LZ_STAMP(4); flush(false); LZ_STAMP(3); }
             lds_sync();
             LZ_STAMP(4);
             const uint32_t dist = rep0 + 1;
             const uint32_t src = p - dist;
             if (src + (F_RING - F_MAX_MATCH) > p + len) {
-                // all of the source is in the ring (and so is the byte behind it)
+                // copy-match (common.lisp:324-333), all lanes: all of the source is in the ring
                 if (dist >= len) {
                     for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                         const uint32_t k = k0 + lane;
@@ -965,47 +891,25 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
                         join_lanes();
                     }
                 }
-                lds_sync();
-                p += len;
-                total += len;
-                prev_v = L.ring[(p - 1 + shift) & F_MASK];
-                mbyte_v = L.ring[(p - 1 - rep0 + shift) & F_MASK];
-            } else if (len < 64) {
-                // dist > len here: lane k takes source byte k, lane len the byte behind the source.  The bytes that
-                // are in HBM only go straight to LDS (the dword around each), and nothing waits for them here.
-                const uint32_t sp = src + (lane <= len ? lane : 0);
-                const bool useg = sp + (F_RING - F_MAX_MATCH) <= p;
-                const uintptr_t a = (uintptr_t)(useg ? ob + sp : safe_byte);
-                pend_sh = useg ? 8 * ((uint32_t)a & 3) : 32;
-                pend_l = L.ring[(sp + shift) & F_MASK];
-                asm volatile("s_mov_b32 m0, %[lds]\n\t"
-                             "s_nop 0\n\t"
-                             "global_load_lds_dword %[a], off sc1"
-                             :
-                             : [lds] "s"(stage_lds), [a] "v"(a & ~(uintptr_t)3)
-                             : "memory", "m0");
-                pend_len = len;
-                pend_p = p;
-                p += len;
-                total += len;
-                LZ_COUNT(3);
+                LZ_COUNT(1);
             } else {
+                // dist > len here; sources older than the ring come from HBM
                 for (uint32_t k0 = 0; k0 < len; k0 += 64) {
                     const uint32_t k = k0 + lane;
-                    const uint32_t sp = src + k;                                   // dist > len
+                    const uint32_t sp = src + k;
                     const bool useg = k < len && sp + (F_RING - F_MAX_MATCH) <= p;
                     const uint32_t gv = __hip_atomic_load(useg ? ob + sp : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t lv = L.ring[(sp + shift) & F_MASK];
                     if (k < len) L.ring[(p + k + shift) & F_MASK] = (uint8_t)(useg ? gv : lv);
                     join_lanes();
                 }
-                lds_sync();
-                p += len;
-                total += len;
-                prev_v = L.ring[(p - 1 + shift) & F_MASK];
-                mbyte_v = history_byte_v(p - 1 - rep0);
                 LZ_COUNT(4);
             }
+            lds_sync();
+            p += len;
+            total += len;
+            prev = uni((uint32_t)L.ring[(p - 1 + shift) & F_MASK]);
+            mbyte = uni(history_byte_v(p - 1 - rep0));
             LZ_STAMP(5);
         }
         if (pend_len) resolve();
@@ -1015,7 +919,6 @@ __global__ __launch_bounds__(64, 2) void lzma2_fast_kernel(const uint8_t *in, ui
         // and the chunk must have used exactly its compressed size (lzma2.lisp:200-201)
         if (code != 0 || s.pos() != chunk_end) { ok = false; WHY(5); break; }
     }
-#undef BIT
     if (!ok) { retry(); return; }
     lds_sync();
     flush(true);

@@ -199,6 +199,11 @@ extern "C" int semz_get_option(semz_ctx *c, const char *name, long *value)
     if (!strcmp(name, "windows")) { *value = (long)c->last_windows; return 0; }
     if (!strcmp(name, "moved")) { *value = (long)c->last_moved; return 0; }
     if (!strcmp(name, "uploaded-bytes")) { *value = (long)c->last_uploaded; return 0; }
+    if (!strcmp(name, "lzma-handed-back")) {
+        if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess || semz_lzma2_handed_back(value))
+            return semz_fail(c, -1, "cannot read the counter");
+        return 0;
+    }
     if (!strcmp(name, "profile")) { *value = c->profile; return 0; }
     if (!strcmp(name, "window-size")) { *value = (long)c->window_size; return 0; }
     return semz_fail(c, -1, "unknown option %s", name);

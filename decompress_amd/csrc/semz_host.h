@@ -100,6 +100,8 @@ size_t semz_bzip2_scratch_per_block();
 // status is decoded by the general kernels of lzma2.hip
 void semz_launch_lzma2_fast(const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits, uint8_t *d_out,
                             size_t out_cap, semz_result *d_results, semz_tail *d_tails, hipStream_t stream);
+// units the fast kernel has handed to the general kernel on the current device since the library was loaded
+int semz_lzma2_handed_back(long *value);
 // wide: literal probabilities in HBM scratch (SEMZ_UNIT_LZMA_WIDE)
 int semz_run_lzma2(semz_ctx *c, const uint8_t *d_in, size_t in_len, const semz_unit *d_units, uint32_t nunits,
                    uint8_t *d_out, size_t out_cap, semz_result *d_results, semz_tail *d_tails, bool wide);

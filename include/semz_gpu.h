@@ -205,8 +205,10 @@ int semz_set_option(semz_ctx *ctx, const char *name, long value);
  * the last read found in the caller's buffer at another place than the stream has them (the walk did not take
  * the prediction as it was) and moved, and "uploaded-bytes": the bytes of input the last stream call sent to
  * devices, all devices of a semz_open_multi context together (every device gets the bytes of its own range; the
- * whole input goes to the primary device only when the walk has to decode something by itself).  No counterpart
- * in the reference. */
+ * whole input goes to the primary device only when the walk has to decode something by itself), and
+ * "lzma-handed-back": how many xz / LZMA2 units the accept-only kernel has handed to the general kernel on this
+ * context's device since the library was loaded (a well-formed block with ordinary properties never is; tests and
+ * measurements take the difference around a call).  No counterpart in the reference. */
 int semz_get_option(semz_ctx *ctx, const char *name, long *value);
 /* Per-kernel device time of the calls since the last reset ("profile" on):
  * spans come in launch order; *name is a static string. */

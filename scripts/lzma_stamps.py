@@ -15,15 +15,16 @@ lib = _lib.load()
 bench.main()
 st = (C.c_ulonglong * 16)()
 assert lib.semz_debug_lz_stamps(st, 1) == 0
-names = ["decode_symbol", "wait for a far match's bytes", "literal: apply", "flush", "match: checks, resolve, sync", "match: copy",
-         "unit end", "loop top / other"]
+names = ["decode_symbols (symbols decoded and applied)", "wait for a far match's bytes (C++ resolve)", "after a run: checks", "flush",
+         "C++ match: resolve, sync", "C++ match: copy", "unit end", "loop top / other"]
 units = st[14] or 1
 tot = sum(st[:8]) or 1
 for i, n in enumerate(names):
-    print(f"{n:32s} {st[i] / units / 1e6:10.3f} Mticks/unit {100 * st[i] / tot:6.1f}%")
-lit, mlit, match, far, _slow = (st[8 + i] / units for i in range(5))
-print(f"per unit: literals {lit:.0f} literals behind a match {mlit:.0f} matches {match:.0f} of them far (deferred) {far:.0f} long far {_slow:.0f}")
-print(f"ticks per symbol: {tot / units / max(1, lit + mlit + match):.0f}; decode_symbol alone {st[0] / units / max(1, lit + mlit + match):.0f}")
+    print(f"{n:48s} {st[i] / units / 1e6:10.3f} Mticks/unit {100 * st[i] / tot:6.1f}%")
+runs_lit, ring, to_cpp, runs_match, far_long = (st[8 + i] / units for i in range(5))
+print(f"per unit: runs ended behind a literal {runs_lit:.0f}, behind a match {runs_match:.0f}, by a match for the C++ code {to_cpp:.0f} "
+      f"(ring copies {ring:.0f}, long far copies {far_long:.0f})")
+print(f"ticks per unit: {tot / units / 1e6:.1f} M; runs per unit: {runs_lit + runs_match + to_cpp:.0f}")
 why = st[15]
-print("units handed to the general kernel, by reason (1 direct bits, 2 end marker, 3 dict size, 4 no data, 5 beyond the chunk):",
-      [(why >> (8 * i)) & 0xFF for i in range(1, 6)], "(counts modulo 256)")
+print("units handed to the general kernel, by reason (1 direct bits, 2 end marker / input beyond the chunk, 3 dict size, 4 no data, "
+      "5 beyond the chunk):", [(why >> (8 * i)) & 0xFF for i in range(1, 6)], "(counts modulo 256)")

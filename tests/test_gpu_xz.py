@@ -67,8 +67,28 @@ def test_multi_block_x86_crc64_and_sha256(engine):
 def test_one_mib_blocks(engine):
     d = corpus.text(3 << 20, seed=6)
     data = xzutil.xz_cli(d, "--block-size=1MiB", "--lzma2=preset=6", "--check=crc64")
+    before = engine.get_option("lzma-handed-back")
     res = check_xz(engine, data, d)
     assert len(res) == 3 and all(r.out_len == 1 << 20 for r in res)
+    assert engine.get_option("lzma-handed-back") == before, "a well-formed block took the general kernel"
+
+
+def test_well_formed_blocks_stay_on_the_fast_kernel(engine):
+    """The accept-only kernel (lzma2_fast.hip) decodes every kind of well-formed block with ordinary properties by
+    itself: text, x86 code behind the BCJ filter, incompressible data (stored chunks), long runs (matches closer than
+    they are long, and the longest ones), every preset's match finder.  What it hands back is decoded correctly by
+    the general kernel all the same, so only this counter shows a fast path that has stopped accepting."""
+    before = engine.get_option("lzma-handed-back")
+    for i, gen in enumerate([corpus.text, corpus.x86ish, corpus.random_bytes, corpus.repetitive, corpus.mixed]):
+        d = gen(700_000, seed=90 + i)
+        for preset in (0, 6, 9):
+            check_xz(engine, xzutil.xz_py(d, lzma.CHECK_CRC64, [{"id": lzma.FILTER_LZMA2, "preset": preset}]), d)
+        check_xz(engine, xzutil.xz_cli(d, "--block-size=262144", "--x86", "--lzma2=preset=6", "--check=crc64"), d)
+    assert engine.get_option("lzma-handed-back") == before
+    # the counter counts: lc + lp = 4 is beyond the fast kernel's literal table
+    d = corpus.text(50_000, seed=99)
+    check_xz(engine, xzutil.xz_py(d, lzma.CHECK_CRC32, [{"id": lzma.FILTER_LZMA2, "preset": 6, "lc": 2, "lp": 2}]), d)
+    assert engine.get_option("lzma-handed-back") == before + 1
 
 
 def test_config4_shape_one_mib_blocks_x86_sha256(engine):
