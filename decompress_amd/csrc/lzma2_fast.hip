@@ -80,9 +80,17 @@ __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); 
     "v_mad_u32_u24 %[t], " vt ", 31, %[k]\n\t"                          \
     "v_lshrrev_b32_e32 %[t], 5, %[t]\n\t"                               \
     "v_cndmask_b32_e64 " vt ", " vt ", %[t], %[mq]\n\t"
-#define A_NORM                                                          \
-    "s_cmp_gt_u32 %[range], 0xffffff\n\t"                               \
-    "s_cbranch_scc1 1f\n\t"                                             \
+// (lzma.lisp:64-73.  One bit step in seven or so needs it, and a taken branch costs as much as three instructions
+// (DESIGN.md 3.0): the common case falls through, the normalisation itself sits out of line in subsection 1 of the
+// text section, each use with labels of its own -- %= numbers the asm statement, __COUNTER__ the use.)
+#define A_NORM A_NORM_N(__COUNTER__, "")
+#define A_NORM_N(n, first) A_NORM_S(n, first)
+#define A_NORM_S(n, first)                                              \
+    "s_cmp_lt_u32 %[range], 0x1000000\n\t"                              \
+    "s_cbranch_scc1 .Lsemz_norm%=_" #n "\n"                             \
+    ".Lsemz_back%=_" #n ":\n\t"                                         \
+    ".subsection 1\n"                                                   \
+    ".Lsemz_norm%=_" #n ":\n\t" first                                   \
     "s_lshr_b32 %[b], %[off], 2\n\t"                                    \
     "s_lshl_b32 %[range], %[range], 8\n\t"                              \
     "v_readlane_b32 %[k], %[win], %[b]\n\t"                             \
@@ -91,8 +99,20 @@ __device__ __forceinline__ void join_lanes() { __builtin_amdgcn_wave_barrier(); 
     "s_lshr_b32 %[k], %[k], %[b]\n\t"                                   \
     "s_and_b32 %[k], %[k], 0xff\n\t"                                    \
     "s_add_u32 %[off], %[off], 1\n\t"                                   \
-    "s_or_b32 %[code], %[code], %[k]\n"                                 \
-    "1:\n\t"
+    "s_or_b32 %[code], %[code], %[k]\n\t"                               \
+    "s_branch .Lsemz_back%=_" #n "\n\t"                                 \
+    ".subsection 0\n\t"
+// One direct bit (lzma.lisp:174-192): the range is halved, f' = 2 f + (bit == 0).  The reference fails when the code
+// equals the halved range after a one bit.  That is the only way for "code < range" to break here, and once broken
+// it stays broken through further halvings (c >= r gives c - (r >> 1) >= r >> 1); a normalisation could shift the
+// evidence out of the 32 bits, so the test is made in front of every normalisation and once behind the last bit
+// rather than at every bit.
+#define A_DIRECT_BIT                                                    \
+    "s_lshr_b32 %[range], %[range], 1\n\t"                              \
+    "s_sub_u32 %[b], %[code], %[range]\n\t" /* SCC = code < range: 0 */ \
+    "s_cselect_b32 %[code], %[code], %[b]\n\t"                          \
+    "s_addc_u32 %[f], %[f], %[f]\n\t"                                   \
+    A_NORM_N(__COUNTER__, "s_cmp_ge_u32 %[code], %[range]\n\ts_cmov_b32 %[bad], 1\n\t")
 #define A_TREE(vt) A_BIT_HEAD(vt) "s_addc_u32 m0, m0, m0\n\t" A_BIT_TAIL(vt) A_NORM                                /* q in M0 */
 #define A_TREEB(vt) "s_add_u32 m0, %[base], %[q]\n\t" A_BIT_HEAD(vt) "s_addc_u32 %[q], %[q], %[q]\n\t" A_BIT_TAIL(vt) A_NORM
 // the last level of an eight-bit tree (q in M0, 128..255), whose 128 models fill two registers: q bit 6 says which
@@ -419,19 +439,21 @@ __device__ __forceinline__ Symbol decode_symbols(uint32_t &range, uint32_t &code
         "s_branch 30f\n"
         // slots 14..63: nb - 4 direct bits (lzma.lisp:174-192), then the four align bits
         "27:\n\t"
-        "s_sub_u32 %[x], %[y], 4\n\t"
-        "s_mov_b32 %[f], 0\n"
+        "s_sub_u32 %[x], %[y], 4\n\t"                    // 2..26 bits: one if the count is odd, then pairs
+        "s_mov_b32 %[f], 0\n\t"
+        "s_lshr_b32 %[base], %[x], 1\n\t"
+        "s_sub_u32 %[base], %[base], 1\n\t"
+        "s_lshl_b32 %[base], 1, %[base]\n\t"             // one bit per pair, shifted out below
+        "s_bitcmp1_b32 %[x], 0\n\t"
+        "s_cbranch_scc0 28f\n\t"
+        A_DIRECT_BIT
         "28:\n\t"
-        "s_lshr_b32 %[range], %[range], 1\n\t"
-        "s_sub_u32 %[b], %[code], %[range]\n\t"          // SCC = code < range: the bit is 0
-        "s_cselect_b32 %[code], %[code], %[b]\n\t"
-        "s_addc_u32 %[f], %[f], %[f]\n\t"
-        "s_cmp_eq_u32 %[code], %[range]\n\t"
-        "s_cmov_b32 %[bad], 1\n\t"
-        A_NORM
-        "s_sub_u32 %[x], %[x], 1\n\t"
-        "s_cmp_lg_u32 %[x], 0\n\t"
+        A_DIRECT_BIT
+        A_DIRECT_BIT
+        "s_lshr_b32 %[base], %[base], 1\n\t"             // SCC = pairs are left
         "s_cbranch_scc1 28b\n\t"
+        "s_cmp_ge_u32 %[code], %[range]\n\t"
+        "s_cmov_b32 %[bad], 1\n\t"
         "s_sub_u32 %[x], %[y], 4\n\t"
         "s_bfm_b32 %[x], %[x], 0\n\t"
         "s_andn2_b32 %[f], %[x], %[f]\n\t"
