@@ -554,21 +554,26 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         const bool islit = lane_of(litmask);
                         const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
                         // the chain of token starts inside the window
-                        // The loop is four instructions per token, written out because the compiler has no way to branch
+                        // The chain is four instructions per token, written out because the compiler has no way to branch
                         // on the carry of a scalar add: `off` runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only
                         // look at its low six bits), so the add carries out exactly when the chain leaves the window.
                         // The s_nop is the wait state gfx950 wants between the VALU write of tbits and a v_readlane of it.
                         mask = 0;
                         uint32_t offb = 0u - 64u, tlen;
+                        // (four steps per pass: a taken branch costs three instructions' time, DESIGN.md 3.0, and a window
+                        // holds five tokens or so)
+#define CHAIN_STEP "v_readlane_b32 %[t], %[tb], %[off]\n\ts_bitset1_b64 %[m], %[off]\n\ts_add_u32 %[off], %[off], %[t]\n\t"
                         asm volatile("s_nop 0\n"
                                      "1:\n\t"
-                                     "v_readlane_b32 %[t], %[tb], %[off]\n\t"
-                                     "s_bitset1_b64 %[m], %[off]\n\t"
-                                     "s_add_u32 %[off], %[off], %[t]\n\t"
-                                     "s_cbranch_scc0 1b"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc0 1b\n"
+                                     "2:"
                                      : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen)
                                      : [tb] "v"(tbits)
                                      : "scc");
+#undef CHAIN_STEP
                         off = offb + 64u;
                         matchmask = mask & ~(stopmask | litmask);
                         // (a token of the chain that the scalar step has to take counts as more bytes than a round holds:

@@ -36,6 +36,8 @@ for fmt in ("gzip", "bzip2", "xz"):
     t = os.path.join(out, "tcc", f"{fmt}_summary.txt")
     if os.path.exists(t):
         with open(os.path.join(prof, f"{tag}_{fmt}_l2_hit_miss.txt"), "w") as f:
-            f.write(f"# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -- python3 bench.py --format {fmt} "
-                    "--steps 2 --warmup 1 --no-cpu --no-e2e --workers 1   (scripts/pmc_tcc_run.sh; requests, not bytes)\n")
+            f.write(f"# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -- python3 bench.py --format {fmt} "
+                    "--formats none --steps 2 --warmup 1 --no-cpu --no-e2e --workers 1 --corpus-cache DIR   (scripts/pmc_tcc_run.sh; "
+                    "requests, not bytes; EA0_RDREQ = reads the L2 sent on, EA0_RDREQ_DRAM = those that went to HBM, the rest "
+                    "were served by the Infinity Cache)\n")
             f.write(open(t).read())

@@ -23,9 +23,10 @@ for fmt in ("gzip", "bzip2", "xz", "xzsha", "zlib"):
     line = [l for l in open(log) if l.startswith("{")][-1]
     d = json.loads(line)
     with open(os.path.join(prof, f"{tag}_{fmt}_kernel_stats.txt"), "w") as f:
-        args = {"xz": "xz --units 16 --replicate 8", "xzsha": "xz --check sha256 --units 16 --replicate 8"}.get(fmt, fmt)
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --format {args} "
-                f"--steps {d['steps']} --warmup {d['warmup']} --no-cpu --no-e2e --workers 1   (MI355X)\n")
+        args = {"xzsha": "xz --check sha256"}.get(fmt, fmt)
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --format {args} --formats none "
+                f"--steps {d['steps']} --warmup {d['warmup']} --no-cpu --no-e2e --workers 1 --corpus-cache DIR   (MI355X; "
+                f"scripts/profile_round.sh)\n")
         f.write(f"# workload: {d['config']['workload']}\n")
         f.write(f"{'kernel':34s} {'calls':>6s} {'total_ms':>10s} {'avg_ms':>9s} {'min_ms':>9s} {'max_ms':>9s} {'pct':>6s}\n")
         for r in rows:

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/tcc/$F
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 170 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum --output-format csv -d $O -o tcc -- \
+timeout -s KILL 170 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $O -o tcc -- \
     python3 $R/bench.py --format $F --steps 2 --warmup 1 --no-cpu --no-e2e --workers 1 "$@" > $O/tcc.log 2>&1
 python3 - "$O" <<'PY'
 import csv, glob, sys, collections
