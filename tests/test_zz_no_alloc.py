@@ -4,7 +4,9 @@ semz_decode_batch_device, through the C ABI.
 Bar (byte work): identical output bytes and identical semz_result records (status, detail,
 consumed bits, length, check value) on two calls in a row, the second with a smaller input,
 so that whatever the first call left in the library's static scratch array cannot leak into
-the second.  The limits of the entry point are checked as API errors.
+the second; and every unit's result equals the CPU oracle's (status, detail of a failure;
+bytes, consumed bits and check value of a success), so the pair cannot be wrong together.
+The limits of the entry point are checked as API errors.
 """
 import ctypes as C
 import random
@@ -14,6 +16,7 @@ import pytest
 
 import corpus
 from decompress_amd import _lib
+from test_gpu_deflate import oracle_unit
 
 pytestmark = pytest.mark.gpu
 
@@ -82,6 +85,17 @@ def test_noalloc_matches_device_entry_twice(engine):
             assert got_out[u.out_off:u.out_off + r.out_len] == want_out[u.out_off:u.out_off + r.out_len]
         # bytes outside the units' spans are untouched by both
         assert got_out == want_out
+        # ... and the oracle says the same, unit by unit
+        fmt_of = {_lib.UNIT_DEFLATE: 0, _lib.UNIT_ZLIB: 1, _lib.UNIT_GZIP: 2}
+        for u, r in zip(units, got):
+            er, eo = oracle_unit(fmt_of[u.kind], data[u.in_off:u.in_limit], u.out_cap)
+            assert r.status == er.status, (r.status, r.detail, er.status, er.detail)
+            if er.status == 0:
+                assert got_out[u.out_off:u.out_off + r.out_len] == eo
+                assert r.in_end_bit - 8 * u.in_off == er.in_end_bit
+                assert bytes(r.check[:r.check_len]) == bytes(er.check[:er.check_len])
+            else:
+                assert r.detail == er.detail, (r.status, r.detail, er.detail)
 
 
 def test_noalloc_limits(engine):
