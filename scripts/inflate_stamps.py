@@ -14,11 +14,13 @@ lib = _lib.load()
 bench.main()
 st = (C.c_ulonglong * 16)()
 assert lib.semz_debug_stamps(st, 1) == 0
-names = ["decode", "far", "raw+near", "flush", "tables+end", "loop-top"]
+names = ["decode", "(unused)", "resolve", "flush", "tables+end", "loop-top"]
 units = st[14] or 1
 tot = sum(st[:6]) or 1
 for i, n in enumerate(names):
-    print(f"{n:10s} {st[i] / units / 1e6:10.3f} Mticks/unit {100 * st[i] / tot:6.1f}%")
+    if n != "(unused)":
+        print(f"{n:10s} {st[i] / units / 1e6:10.3f} Mticks/unit {100 * st[i] / tot:6.1f}%")
 win, tok, careful, rounds, far, near = (st[6 + i] / units for i in range(6))
-print(f"per unit: windows {win:.0f} window tokens {tok:.0f} ({tok / max(1, win):.2f} per window) scalar steps {careful:.0f} rounds {rounds:.0f} far {far:.0f} near {near:.0f}")
+print(f"per unit: windows {win:.0f} window tokens {tok:.0f} ({tok / max(1, win):.2f} per window) scalar steps {careful:.0f} rounds {rounds:.0f} "
+      f"matches resolved together (source in front of the round) {far:.0f}, one after the other (source inside the round) {near:.0f}")
 print(f"ticks per token: total {tot / units / max(1, tok + careful):.0f}  decode only {st[0] / units / max(1, tok + careful):.0f}")
