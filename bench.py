@@ -88,42 +88,54 @@ def describe(fmt, nunits, unit_bytes, rep, check):
 
 
 # ---------------------------------------------------------------- corpus (host only, before the GPU is touched)
+# The value distribution of the plaintext: Zipf word text is what the metric is quoted on;
+# incompressible bytes (stored blocks) and highly repetitive bytes (long matches, run-length heavy) are the two
+# robustness distributions (--data).  Forked pool workers inherit the setting.
+DATA_KINDS = ("text", "random", "repetitive")
+_DATA = "text"
+
+
+def _plain(n, seed, x86=False):
+    import corpus
+    if _DATA == "random":
+        return corpus.random_bytes(n, seed=seed)
+    if _DATA == "repetitive":
+        return corpus.repetitive(n, seed=seed)
+    return corpus.x86ish(n, seed=seed) if x86 else corpus.text(n, seed=seed)
+
+
 def _make_gzip_members(args):
     """Worker: members [lo, hi) of the corpus -> list of gzip -6 blobs."""
-    import corpus
     lo, hi, unit_bytes, seed = args
     out = []
     for i in range(lo, hi):
-        d = corpus.text(unit_bytes, seed=seed + i)
+        d = _plain(unit_bytes, seed + i)
         co = zlib.compressobj(6, zlib.DEFLATED, 31)
         out.append(co.compress(d) + co.flush())
     return out
 
 
 def _make_zlib_records(args):
-    import corpus
     lo, hi, unit_bytes, seed = args
-    big = corpus.text((hi - lo) * unit_bytes, seed=seed + lo)
+    big = _plain((hi - lo) * unit_bytes, seed + lo)
     return [zlib.compress(big[k * unit_bytes:(k + 1) * unit_bytes], 6) for k in range(hi - lo)]
 
 
 def _make_bzip2_streams(args):
     """bzip2 -9 streams of `unit_bytes` each (several 900k blocks per stream)."""
     import bz2
-    import corpus
     lo, hi, unit_bytes, seed = args
-    return [bz2.compress(corpus.text(unit_bytes, seed=seed + i), 9) for i in range(lo, hi)]
+    return [bz2.compress(_plain(unit_bytes, seed + i), 9) for i in range(lo, hi)]
 
 
 def _make_xz_streams(args):
     """xz streams with 1 MiB blocks, x86 BCJ + LZMA2 preset 6 and the given block check, through the xz tool
     (CPython's lzma writes one block per stream)."""
     import subprocess
-    import corpus
     lo, hi, unit_bytes, seed, check = args
     out = []
     for i in range(lo, hi):
-        d = corpus.x86ish(unit_bytes, seed=seed + i)
+        d = _plain(unit_bytes, seed + i, x86=True)
         out.append(subprocess.run(["xz", "-c", "-T1", "--block-size=1MiB", "--x86", "--lzma2=preset=6", f"--check={check}"],
                                   input=d, stdout=subprocess.PIPE, check=True).stdout)
     return out
@@ -158,7 +170,7 @@ def make_blobs(fmt, nunits, unit_bytes, seed, workers, check="crc64", cache=None
     (the xz tool, pool workers) after the profiler has initialised the GPU."""
     path = None
     if cache:
-        path = os.path.join(cache, f"{fmt}_{first}+{nunits}x{unit_bytes}_{seed:x}_{check if fmt == 'xz' else 'x'}.npz")
+        path = os.path.join(cache, f"{fmt}_{_DATA}_{first}+{nunits}x{unit_bytes}_{seed:x}_{check if fmt == 'xz' else 'x'}.npz")
         if os.path.exists(path):
             z = np.load(path)
             ends = np.cumsum(z["lengths"])
@@ -367,7 +379,7 @@ def roofline(fmt, W, unit_bytes, spans, steps, ms_step):
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     pmc_key = f"{fmt}:{nun}x{unit_bytes}:{kname}"
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and _DATA == "text":        # (the passes were made on the text corpus)
         with open(pmc_path) as f:
             ent = json.load(f).get(pmc_key)
         if ent:
@@ -509,7 +521,12 @@ def main():
                     help="directory that keeps generated corpora between runs on one box (runs under rocprofv3 read it "
                          "instead of starting child processes)")
     ap.add_argument("--make-corpus", action="store_true", help="fill --corpus-cache for the selected workloads and exit (no GPU)")
+    ap.add_argument("--data", default="text", choices=DATA_KINDS,
+                    help="value distribution of the plaintext: the Zipf text of the metric, or one of the two robustness "
+                         "distributions of SURVEY.md section 8d (incompressible, highly repetitive)")
     a = ap.parse_args()
+    global _DATA
+    _DATA = a.data
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -655,7 +672,8 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "format": a.format, "units_per_gpu": W["nunits"], "unit_bytes": unit_bytes,
                        "compressed_bytes_per_gpu": W["total_in"], "decompressed_bytes_per_gpu": W["total_out"],
-                       "sharding": f"units by rank x{world}, no collective", "corpus_gen_s": round(t_gen, 1)},
+                       "sharding": f"units by rank x{world}, no collective", "corpus_gen_s": round(t_gen, 1),
+                       "plaintext": a.data},
             "verified": verified,
             "roofline": roofline(a.format, W, unit_bytes, spans, a.steps, ms_step),
         }

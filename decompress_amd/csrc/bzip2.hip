@@ -611,8 +611,8 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
         // wait for the MTF alphabet (or for a header that failed)
         while (!BZ_LD(L.sh.hdr_ready) && !BZ_LD(L.sh.done)) __builtin_amdgcn_s_sleep(8);
         if (BZ_LD(L.sh.hdr_ready)) {
-            // inverse-MTF list: lane i of mtf_a holds entry i < 64; entries 64 .. 255 stay in L.symbols
-            uint32_t mtf_a = L.symbols[lane];
+            // inverse-MTF list: lane i of mtf_a holds entry i < 64, mtf_b .. mtf_d entries 64 .. 255
+            uint32_t mtf_a = L.symbols[lane], mtf_b = L.symbols[64 + lane], mtf_c = L.symbols[128 + lane], mtf_d = L.symbols[192 + lane];
             uint32_t ab_len = 0, ab_val = 0, consumed = 0, produced_seen = 0;
             // mtfq entry: MTF index (8 bits) | length of the run in front of it << 8 (at most 2^20 - 1), or:
             constexpr uint32_t CV_LONG = 1u << 31;       // more run digits than +bzip2-ab-bound+
@@ -707,32 +707,78 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                     for (; e + 2 <= cnt; e += 2) { step(e); step(e + 1); }
                     for (; e < cnt; e++) step(e);
                 } else {
+                    // Indexes of 64 and more (incompressible data: three symbols in four): the whole list is in four
+                    // registers, entry 64 k + l in lane l of register k.  The entries in front of the index move up by
+                    // one: whole registers shift with the last lane of the register before them coming in at lane 0,
+                    // the register that holds the index shifts up to the index's lane.  (With entries 64.. in LDS
+                    // a symbol cost three LDS round trips: 192 ms per launch for blocks of random bytes, now 52.)
+                    // One block of assembler with the four cases inside (written as four blocks under C++ branches the
+                    // compiler copied the five registers around every one of them): the carries are taken first, the
+                    // registers shift in place (lane 0 keeps its value), v_writelane puts what comes in at lane 0,
+                    // and the symbol's byte goes into lane e of xv.  (Wait states: a DPP source must not have been
+                    // written by the two instructions before it; no lane select here comes out of a vector
+                    // instruction less than five instructions earlier.)
+#define BZ_DPP_SHR(r) "v_mov_b32_dpp " r ", " r " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define BZ_DPP_TMP(r) "v_mov_b32_dpp %[t], " r " wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                     for (uint32_t e = 0; e < cnt; e++) {
                         const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
-                        uint32_t x;
-                        if (idx < 64) {
-                            x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
-                        } else {
-                            // entries [64, idx) move up by one inside LDS, entry 63 follows them, then the VGPR shifts
-                            x = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)L.symbols[idx & 255]);
-                            uint32_t v[3];
-                            for (int c3 = 0; c3 < 3; c3++) {
-                                const uint32_t p = 64 + 64 * c3 + lane;
-                                v[c3] = p < idx ? L.symbols[p] : 0u;
-                            }
-                            lds_sync();
-                            for (int c3 = 0; c3 < 3; c3++) {
-                                const uint32_t p = 64 + 64 * c3 + lane;
-                                if (p < idx && p < 255) L.symbols[p + 1] = (uint8_t)v[c3];
-                            }
-                            if (lane == 63) L.symbols[64] = (uint8_t)mtf_a;
-                            __builtin_amdgcn_wave_barrier();
-                            lds_sync();
-                        }
-                        const uint32_t sh = shr1(mtf_a, x);
-                        mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;      // an index of 64 and more shifts every lane
-                        xv = (uint32_t)lane == e ? x : xv;
+                        uint32_t x, c0, c1, c2, j, t;
+                        asm volatile("s_mov_b32 m0, %[e]\n\t"
+                                     "s_and_b32 %[j], %[idx], 63\n\t"
+                                     "v_cmp_ge_u32_e32 vcc, %[j], %[lane]\n\t"
+                                     "s_cmp_lt_u32 %[idx], 128\n\t"
+                                     "s_cbranch_scc0 2f\n\t"
+                                     "s_cmp_lt_u32 %[idx], 64\n\t"
+                                     "s_cbranch_scc0 1f\n\t"
+                                     // 0 .. 63
+                                     "v_readlane_b32 %[x], %[a], %[j]\n\t"
+                                     BZ_DPP_TMP("%[a]")
+                                     "v_writelane_b32 %[t], %[x], 0\n\t"
+                                     "v_writelane_b32 %[xv], %[x], m0\n\t"
+                                     "v_cndmask_b32_e32 %[a], %[a], %[t], vcc\n\t"
+                                     "s_branch 9f\n"
+                                     "1:\n\t"       // 64 .. 127
+                                     "v_readlane_b32 %[x], %[b], %[j]\n\t"
+                                     "v_readlane_b32 %[c0], %[a], 63\n\t"
+                                     BZ_DPP_TMP("%[b]") BZ_DPP_SHR("%[a]")
+                                     "v_writelane_b32 %[t], %[c0], 0\n\t"
+                                     "v_writelane_b32 %[xv], %[x], m0\n\t"
+                                     "v_writelane_b32 %[a], %[x], 0\n\t"
+                                     "v_cndmask_b32_e32 %[b], %[b], %[t], vcc\n\t"
+                                     "s_branch 9f\n"
+                                     "2:\n\t"
+                                     "s_cmp_lt_u32 %[idx], 192\n\t"
+                                     "s_cbranch_scc0 3f\n\t"
+                                     // 128 .. 191
+                                     "v_readlane_b32 %[x], %[c], %[j]\n\t"
+                                     "v_readlane_b32 %[c0], %[a], 63\n\t"
+                                     "v_readlane_b32 %[c1], %[b], 63\n\t"
+                                     BZ_DPP_TMP("%[c]") BZ_DPP_SHR("%[a]") BZ_DPP_SHR("%[b]")
+                                     "v_writelane_b32 %[t], %[c1], 0\n\t"
+                                     "v_writelane_b32 %[xv], %[x], m0\n\t"
+                                     "v_writelane_b32 %[a], %[x], 0\n\t"
+                                     "v_writelane_b32 %[b], %[c0], 0\n\t"
+                                     "v_cndmask_b32_e32 %[c], %[c], %[t], vcc\n\t"
+                                     "s_branch 9f\n"
+                                     "3:\n\t"       // 192 .. 255
+                                     "v_readlane_b32 %[x], %[d], %[j]\n\t"
+                                     "v_readlane_b32 %[c0], %[a], 63\n\t"
+                                     "v_readlane_b32 %[c1], %[b], 63\n\t"
+                                     "v_readlane_b32 %[c2], %[c], 63\n\t"
+                                     BZ_DPP_TMP("%[d]") BZ_DPP_SHR("%[a]") BZ_DPP_SHR("%[b]") BZ_DPP_SHR("%[c]")
+                                     "v_writelane_b32 %[t], %[c2], 0\n\t"
+                                     "v_writelane_b32 %[xv], %[x], m0\n\t"
+                                     "v_writelane_b32 %[a], %[x], 0\n\t"
+                                     "v_writelane_b32 %[b], %[c0], 0\n\t"
+                                     "v_writelane_b32 %[c], %[c1], 0\n\t"
+                                     "v_cndmask_b32_e32 %[d], %[d], %[t], vcc\n"
+                                     "9:"
+                                     : [a] "+v"(mtf_a), [b] "+v"(mtf_b), [c] "+v"(mtf_c), [d] "+v"(mtf_d), [xv] "+v"(xv), [x] "=&s"(x),
+                                       [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [j] "=&s"(j), [t] "=&v"(t)
+                                     : [idx] "s"(idx), [e] "s"(e), [lane] "v"(lane) : "vcc", "scc", "m0");
                     }
+#undef BZ_DPP_SHR
+#undef BZ_DPP_TMP
                 }
                 // ---- layout: symbol e puts its run, then its byte
                 const bool live = (uint32_t)lane < cnt;
