@@ -448,12 +448,31 @@ def end_to_end(eng, fmt, W, windowed=True, batch_budget=0):
     return line
 
 
-def timed_steps(dw, steps, barrier):
+def timed_steps(dw, steps, barrier, per_step=None):
+    """K steps between two barriers, wall clock.  `per_step` (a list) also receives every step's device time: an event
+    on the engine's stream behind each step (SURVEY.md section 8d asks for best and median next to the mean)."""
+    eng = dw.eng
+    evs = [eng.event() for _ in range(steps + 1)] if per_step is not None else None
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if evs:
+        eng.record(evs[0])
+    for i in range(steps):
         dw.step()
+        if evs:
+            eng.record(evs[i + 1])
     barrier()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if evs:
+        per_step.extend(eng.elapsed_ms(evs[i], evs[i + 1]) for i in range(steps))
+        for e in evs:
+            eng.lib.semz_event_destroy(eng.h, e)
+    return dt
+
+
+def step_stats(per_step):
+    v = sorted(per_step)
+    return {"best": round(v[0], 4), "median": round(v[len(v) // 2] if len(v) % 2 else (v[len(v) // 2 - 1] + v[len(v) // 2]) / 2, 4),
+            "worst": round(v[-1], 4), "unit": "ms", "how": "device time between events behind consecutive steps"}
 
 
 def run_format(eng, name, spec, W, cpu_line, steps, warmup, t_gen, e2e=True):
@@ -466,7 +485,8 @@ def run_format(eng, name, spec, W, cpu_line, steps, warmup, t_gen, e2e=True):
             dw.step()
         eng.sync()
         eng.set_option("profile", 0)
-        dt = timed_steps(dw, steps, eng.sync)       # the rate: no event pairs, kernels of large bzip2 batches overlap
+        per_step = []
+        dt = timed_steps(dw, steps, eng.sync, per_step)   # the rate: no event pairs inside a step, kernels of large bzip2 batches overlap
         eng.set_option("profile", 1)
         eng.profile()
         pk = max(2, min(steps, 5))
@@ -478,7 +498,7 @@ def run_format(eng, name, spec, W, cpu_line, steps, warmup, t_gen, e2e=True):
         dw.free()
     ms_step = dt / steps * 1e3
     ent = {"value": round(W["total_out"] / (dt / steps) / 1e9, 3), "unit": "GB/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": round(ms_step, 4),
+           "ms_per_step": round(ms_step, 4), "step_ms": step_stats(per_step),
            "config": {"workload": describe(fmt, spec["units"], unit_bytes, spec.get("replicate", 1), spec.get("check", "crc64")),
                       "units_per_gpu": W["nunits"], "compressed_bytes_per_gpu": W["total_in"],
                       "decompressed_bytes_per_gpu": W["total_out"], "corpus_gen_s": round(t_gen, 1)},
@@ -639,7 +659,8 @@ def main():
     barrier()
     eng.set_option("profile", 0 if a.no_spans else 1)
     eng.profile()
-    dt = timed_steps(dw, a.steps, barrier)
+    per_step = []
+    dt = timed_steps(dw, a.steps, barrier, per_step)
     spans = eng.profile()
     eng.set_option("profile", 0)
     if dist is not None:
@@ -668,7 +689,8 @@ def main():
         value = world * W["total_out"] / (dt / a.steps) / 1e9
         line = {
             "metric": METRIC, "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": round(ms_step, 4), "step_ms": step_stats(per_step), "higher_is_better": True,
+            "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "format": a.format, "units_per_gpu": W["nunits"], "unit_bytes": unit_bytes,
                        "compressed_bytes_per_gpu": W["total_in"], "decompressed_bytes_per_gpu": W["total_out"],
