@@ -39,8 +39,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # what the SQ counters (profiles/*_pmc_sq.txt) say bounds the dominant kernel in practice
 ISSUE_NOTES = {
     "gzip": "instruction-issue bound, the scalar unit first (four waves per SIMD share it and take turns at its priorities); "
-            "traffic above the algorithmic bytes is one 128-byte line per far match from the Infinity Cache (DESIGN.md section 3.1)",
-    "zlib": "instruction-issue bound like gzip, plus a table build per 4 KiB record (DESIGN.md section 3.1)",
+            "traffic above the algorithmic bytes is one line per far match, re-read through L2 (DESIGN.md section 3.1)",
+    "zlib": "instruction-issue bound like gzip at 2.3 bytes per token instead of 4.9, plus a table build per 4 KiB record "
+            "(DESIGN.md section 3.1)",
     "bzip2": "bz_decode_kernel: the latency of two serial waves per block; bz_walk_kernel: one dependent 4-byte read per output "
              "byte out of the XCD's L2 (DESIGN.md section 3.2)",
     "xz": "serial range decoder, instruction-issue bound with two waves per SIMD (DESIGN.md section 3.3)",
