@@ -711,7 +711,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                     // registers, entry 64 k + l in lane l of register k.  The entries in front of the index move up by
                     // one: whole registers shift with the last lane of the register before them coming in at lane 0,
                     // the register that holds the index shifts up to the index's lane.  (With entries 64.. in LDS
-                    // a symbol cost three LDS round trips: 192 ms per launch for blocks of random bytes, now 52.)
+                    // a symbol cost three LDS round trips: 192 ms per launch for blocks of random bytes, now 99.)
                     // One block of assembler with the four cases inside (written as four blocks under C++ branches the
                     // compiler copied the five registers around every one of them): the carries are taken first, the
                     // registers shift in place (lane 0 keeps its value), v_writelane puts what comes in at lane 0,
