@@ -690,22 +690,44 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 const uint32_t idxv = cv & 0xFF;
                 uint32_t xv = 0;
                 if (__builtin_amdgcn_ballot_w64(idxv >= 64) == 0) {
-                    // every index of the batch lies inside the register: a loop without any other path
-                    // (four symbols between two jumps back, the byte put into its lane with one v_writelane: this
-                    // loop is the wave's chain, 900 k times per block)
-                    auto step = [&](uint32_t e) {
-                        const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)idxv, (int)e);
-                        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)mtf_a, (int)idx);
-                        const uint32_t sh = shr1(mtf_a, x);
-                        mtf_a = (uint32_t)lane <= idx ? sh : mtf_a;
-                        // (x comes out of a v_readlane: the wait states between a VALU write of an SGPR and its use
-                        // by a lane instruction are written out, nobody inserts them inside an asm statement)
-                        asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tv_writelane_b32 %0, %1, m0" : "+v"(xv) : "s"(x), "s"(e) : "m0");
-                    };
-                    uint32_t e = 0;
-                    for (; e + 8 <= cnt; e += 8) { step(e); step(e + 1); step(e + 2); step(e + 3); step(e + 4); step(e + 5); step(e + 6); step(e + 7); }
-                    for (; e + 2 <= cnt; e += 2) { step(e); step(e + 1); }
-                    for (; e < cnt; e++) step(e);
+                    // every index of the batch lies inside the first register: a loop without any other path, the
+                    // wave's chain, 900 k times per block, and one block of assembler: eight instructions per symbol.
+                    // m0 runs one ahead of the symbol (the index of the next symbol is read with it, five
+                    // instructions before it is used as a lane select), so the byte of symbol e lands in lane e + 1
+                    // of xv (symbol 63: lane 0) and one rotation puts the batch right afterwards.
+#define BZ_MTF_STEP                                                                         \
+    "s_add_u32 m0, m0, 1\n\t"                                                               \
+    "v_readlane_b32 %[x], %[a], %[i]\n\t"                                                    \
+    "v_cmp_ge_u32_e32 vcc, %[i], %[lane]\n\t"                                                \
+    "v_readlane_b32 %[i], %[iv], m0\n\t"                                                     \
+    "v_mov_b32_dpp %[t], %[a] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"                     \
+    "v_writelane_b32 %[xv], %[x], m0\n\t"                                                    \
+    "v_writelane_b32 %[t], %[x], 0\n\t"                                                      \
+    "v_cndmask_b32_e32 %[a], %[a], %[t], vcc\n\t"
+                    uint32_t x, i, t, lim;
+                    asm volatile("s_mov_b32 m0, 0\n\t"
+                                 "v_readlane_b32 %[i], %[iv], 0\n\t"
+                                 "s_sub_u32 %[lim], %[cnt], 3\n\t"
+                                 "s_cmp_lt_u32 %[cnt], 4\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_nop 0\n"
+                                 "1:\n\t"
+                                 BZ_MTF_STEP BZ_MTF_STEP BZ_MTF_STEP BZ_MTF_STEP
+                                 "s_cmp_lt_u32 m0, %[lim]\n\t"
+                                 "s_cbranch_scc1 1b\n"
+                                 "2:\n\t"
+                                 "s_cmp_lt_u32 m0, %[cnt]\n\t"
+                                 "s_cbranch_scc0 4f\n"
+                                 "3:\n\t"
+                                 BZ_MTF_STEP
+                                 "s_cmp_lt_u32 m0, %[cnt]\n\t"
+                                 "s_cbranch_scc1 3b\n"
+                                 "4:"
+                                 : [a] "+v"(mtf_a), [xv] "+v"(xv), [x] "=&s"(x), [i] "=&s"(i), [t] "=&v"(t), [lim] "=&s"(lim)
+                                 : [iv] "v"(idxv), [lane] "v"(lane), [cnt] "s"(cnt)
+                                 : "vcc", "scc", "m0");
+#undef BZ_MTF_STEP
+                    xv = (uint32_t)__builtin_amdgcn_update_dpp((int)xv, (int)xv, 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
                 } else {
                     // Indexes of 64 and more (incompressible data: three symbols in four): the whole list is in four
                     // registers, entry 64 k + l in lane l of register k.  The entries in front of the index move up by
