@@ -149,7 +149,7 @@ struct BzShare {           // producer/consumer hand-over (LDS, workgroup-scope 
 };
 
 template <int BZ_ROOT_BITS> struct __align__(16) BzLds {
-    uint8_t inbuf[BZ_IN_RING];
+    uint8_t inbuf[BZ_IN_RING + 16];      // the first 16 bytes again behind the end: a window's second dword never wraps
     BzTree<BZ_ROOT_BITS> tree[6];
     uint8_t lens[260];
     uint8_t symbols[256];
@@ -220,6 +220,8 @@ struct MsbReader {
         }
         lds_sync();
         *reinterpret_cast<uint4 *>(ring + ((uint32_t)s_hi & (BZ_IN_RING - 1)) + 16 * lane) = x;
+        if (((uint32_t)s_hi & (BZ_IN_RING - 1)) == 0 && lane == 0) *reinterpret_cast<uint4 *>(ring + BZ_IN_RING) = x;   // (the mirror)
+        __builtin_amdgcn_wave_barrier();
         lds_sync();
         s_hi += BZ_IN_HALF;
     }
@@ -459,10 +461,13 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
             const uint64_t endbits = 8 * br.limit;
             const uint32_t *ring32 = reinterpret_cast<const uint32_t *>(L.inbuf);
             uint32_t produced = 0, consumed_seen = 0;
-            uint32_t g = 0, k = BZ_GROUP, t = 0, maxlen = 0;
+            uint32_t g = 0, k = BZ_GROUP, t = 0;
             uint32_t selw = 0, selblk = ~0u;                // lane j: the 8 selectors 512 selblk + 8 j ..
             P = br.bitpos();
             in_symbols = true;
+            // (the block of assembler below writes LDS addresses as immediates: this kernel's only LDS object starts at 0)
+            const bool lds_at_0 = (uint32_t)__builtin_amdgcn_readfirstlane(
+                                      (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.inbuf) == 0;
             BZ_STAMP(0);
             for (;;) {
                 // room for one more window of symbols?
@@ -485,12 +490,153 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                         selw = __hip_atomic_load(selg + 64 * selblk + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     t = ((uint32_t)__builtin_amdgcn_readlane((int)selw, (int)((g >> 3) & 63)) >> (4 * (g & 7))) & 15;
-                    maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.tree[t].maxlen);
                     g++;
                     k = 0;
                 }
                 const BzTree<BZ_ROOT_BITS> &T = L.tree[t];
                 while ((P >> 3) + 16 > br.s_hi) { br.stage(); BZ_COUNT(3); }
+                // ---- runs of ordinary windows, one block of assembler ----
+                // Nearly every window has nothing to it: every code of the chain fits the root table, the block does
+                // not end, input is staged and the queue has room.  Written in C++ such a window is ~100 instructions
+                // and nine taken branches around its 15 chain steps (the compiler keeps every condition as a flag
+                // register and branches on it twice); here it is 50 and one.  The block takes the step from one group
+                // to the next (the selector's tree) and cuts a window at the end of a group by itself; it commits
+                // what it takes of a window at once and leaves in front of the first window it does not take -- a
+                // long code or the end of the block in the chain, the queue looking full, the staged input running
+                // out, a group at which the wave takes its turn or fetches selectors -- without having touched it:
+                // the code below (or the top of the loop) deals with that one as before.
+                if (lds_at_0) {
+                    const int64_t b1 = (int64_t)(8 * br.s_hi) - 128 - (int64_t)P;            // staged bits ahead
+                    const int64_t b2 = (int64_t)(endbits - P) - (64 + 20);                    // bits before the input's last ones
+                    const int64_t b = b1 < b2 ? b1 : b2;
+                    if (b >= 0) {
+                        int32_t bud = b < 0x7FFFFFFF ? (int32_t)b : 0x7FFFFFFF;
+                        uint32_t pr = (uint32_t)P;
+                        const uint32_t pr0 = pr, produced0 = produced;
+                        (void)produced0;
+                        constexpr uint32_t TREES = __builtin_offsetof(BzLds<BZ_ROOT_BITS>, tree), TREE_SIZE = sizeof(BzTree<BZ_ROOT_BITS>);
+                        uint32_t rootb = TREES + t * TREE_SIZE;
+                        uint32_t x, y, off, cnt, len_s, wins = 0, bp, a0, sh, evv, lenv2, sym, zero;
+                        uint64_t longm2, xx;
+                        asm volatile(
+                            "v_mov_b32_e32 %[zero], 0\n"
+                            "10:\n\t"
+                            "s_cmp_lt_i32 %[bud], 0\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            "s_sub_u32 %[x], %[prod], %[cons]\n\t"
+                            "s_cmp_gt_u32 %[x], %[room]\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            "s_cmp_lt_u32 %[k], %[group]\n\t"
+                            "s_cbranch_scc1 11f\n\t"
+                            // the next group: its selector is four bits of lane (g >> 3) & 63 of selw
+                            "s_cmp_ge_u32 %[g], %[nsel]\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            "s_and_b32 %[x], %[g], 31\n\t"
+                            "s_cmp_eq_u32 %[x], 0\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            "s_lshr_b32 %[x], %[g], 9\n\t"
+                            "s_cmp_lg_u32 %[x], %[selblk]\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            "s_lshr_b32 %[x], %[g], 3\n\t"
+                            "s_lshl_b32 %[y], %[g], 2\n\t"
+                            "v_readlane_b32 %[x], %[selw], %[x]\n\t"
+                            "s_add_u32 %[g], %[g], 1\n\t"
+                            "s_mov_b32 %[k], 0\n\t"
+                            "s_lshr_b32 %[x], %[x], %[y]\n\t"
+                            "s_and_b32 %[tree], %[x], 15\n\t"
+                            "s_mul_i32 %[x], %[tree], %[tsize]\n\t"
+                            "s_add_u32 %[rootb], %[x], %[trees]\n"
+                            "11:\n\t"
+                            // lane l: the 32 bits from bit P + l on, and the root entry of their top bits
+                            "v_add_u32_e32 %[bp], %[pr], %[lane]\n\t"
+                            "v_lshrrev_b32_e32 %[a0], 3, %[bp]\n\t"
+                            "v_and_b32_e32 %[a0], 0x7fc, %[a0]\n\t"
+                            "ds_read2_b32 v[40:41], %[a0] offset1:1\n\t"
+                            "v_and_b32_e32 %[sh], 31, %[bp]\n\t"
+                            "s_mov_b64 s[96:97], 0\n\t"
+                            "s_movk_i32 %[off], 0xffc0\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_perm_b32 v43, 0, v40, %[sel]\n\t"
+                            "v_perm_b32 v42, 0, v41, %[sel]\n\t"
+                            "v_lshlrev_b64 v[42:43], %[sh], v[42:43]\n\t"
+                            "v_lshrrev_b32_e32 %[a0], %[rsh], v43\n\t"
+                            "v_lshl_add_u32 %[a0], %[a0], 1, %[rootb]\n\t"
+                            "ds_read_u16 %[ev], %[a0]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_and_b32_e32 %[lenv], 31, %[ev]\n\t"
+                            "v_cmp_eq_u32_e64 %[longm], 0, %[lenv]\n\t"
+                            "v_cndmask_b32_e64 %[lenv], %[lenv], 64, %[longm]\n\t"
+                            "v_lshrrev_b32_e32 %[sym], 5, %[ev]\n"
+                            // the chain of symbol starts (see below)
+                            "1:\n\t"
+#define BZ_RUN_STEP "v_readlane_b32 %[t], %[lenv], %[off]\n\ts_bitset1_b64 s[96:97], %[off]\n\ts_add_u32 %[off], %[off], %[t]\n\ts_cbranch_scc1 2f\n\t"
+                            BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP BZ_RUN_STEP
+#undef BZ_RUN_STEP
+                            "s_branch 1b\n"
+                            "2:\n\t"
+                            // a0 = how many symbols start below the lane
+                            "s_bcnt1_i32_b64 %[cnt], s[96:97]\n\t"
+                            "v_mbcnt_lo_u32_b32 %[a0], s96, 0\n\t"
+                            "s_add_u32 %[x], %[k], %[cnt]\n\t"
+                            "v_mbcnt_hi_u32_b32 %[a0], s97, %[a0]\n\t"
+                            "s_cmp_gt_u32 %[x], %[group]\n\t"
+                            "s_cbranch_scc0 3f\n\t"
+                            // the group ends inside the window: the start with `group - k` starts below it is the
+                            // next group's first symbol, and the window ends there
+                            "s_sub_u32 %[cnt], %[group], %[k]\n\t"
+                            "v_cmp_eq_u32_e32 vcc, %[cnt], %[a0]\n\t"
+                            "s_and_b64 %[xx], vcc, s[96:97]\n\t"
+                            "s_ff1_i32_b64 %[x], %[xx]\n\t"
+                            "s_bfm_b64 %[xx], %[x], 0\n\t"
+                            "s_sub_u32 %[off], %[x], 64\n\t"
+                            "s_and_b64 s[96:97], s[96:97], %[xx]\n\t"
+                            "s_mov_b32 %[x], %[group]\n"
+                            "3:\n\t"
+                            // a long code or the end of the block in what is left of the chain: not this block's
+                            "v_cmp_eq_u32_e32 vcc, %[eob], %[sym]\n\t"
+                            "s_or_b64 %[xx], vcc, %[longm]\n\t"
+                            "s_and_b64 %[xx], %[xx], s[96:97]\n\t"
+                            "s_cmp_lg_u64 %[xx], 0\n\t"
+                            "s_cbranch_scc1 90f\n\t"
+                            // taken: the symbols go to the queue in order, the counters move on
+                            "s_mov_b32 %[k], %[x]\n\t"
+                            "v_add_u32_e32 %[a0], %[prod], %[a0]\n\t"
+                            "v_and_b32_e32 %[a0], %[qmask], %[a0]\n\t"
+                            "v_lshlrev_b32_e32 %[a0], 1, %[a0]\n\t"
+                            "s_mov_b64 exec, s[96:97]\n\t"
+                            "ds_write_b16 %[a0], %[sym] offset:%[symq]\n\t"
+                            "s_mov_b64 exec, -1\n\t"
+                            "s_add_u32 %[prod], %[prod], %[cnt]\n\t"
+                            "s_add_u32 %[off], %[off], 64\n\t"
+                            "s_add_u32 %[wins], %[wins], 1\n\t"
+                            "s_add_u32 %[pr], %[pr], %[off]\n\t"
+                            "s_sub_u32 %[bud], %[bud], %[off]\n\t"
+                            "v_mov_b32_e32 %[a0], %[prod]\n\t"
+                            // (LDS operations of a wave are carried out in order: the count follows the symbols)
+                            "ds_write_b32 %[zero], %[a0] offset:%[prodat]\n\t"
+                            "s_branch 10b\n"
+                            "90:\n\t"
+                            : [pr] "+s"(pr), [bud] "+s"(bud), [k] "+s"(k), [g] "+s"(g), [tree] "+s"(t), [rootb] "+s"(rootb),
+                              [prod] "+s"(produced), [wins] "+s"(wins), [x] "=&s"(x), [y] "=&s"(y),
+                              [off] "=&s"(off), [cnt] "=&s"(cnt), [t] "=&s"(len_s), [longm] "=&s"(longm2), [xx] "=&s"(xx),
+                              [bp] "=&v"(bp), [a0] "=&v"(a0), [sh] "=&v"(sh), [ev] "=&v"(evv), [lenv] "=&v"(lenv2), [sym] "=&v"(sym),
+                              [zero] "=&v"(zero)
+                            : [cons] "s"(consumed_seen), [eob] "s"(eob), [sel] "s"(0x00010203u), [lane] "v"((uint32_t)lane),
+                              [nsel] "s"(nsel), [selblk] "s"(selblk), [selw] "v"(selw),
+                              [room] "i"(BZ_QCAP - 64), [group] "i"(BZ_GROUP), [qmask] "i"(BZ_QCAP - 1), [rsh] "i"(32 - BZ_ROOT_BITS),
+                              [trees] "i"(TREES), [tsize] "i"(TREE_SIZE),
+                              [symq] "i"(__builtin_offsetof(BzLds<BZ_ROOT_BITS>, symq)),
+                              [prodat] "i"(__builtin_offsetof(BzLds<BZ_ROOT_BITS>, sh) + __builtin_offsetof(BzShare, produced))
+                            : "scc", "vcc", "memory", "v40", "v41", "v42", "v43", "s96", "s97");
+                        P += (uint32_t)(pr - pr0);
+#ifdef SEMZ_STAMPS
+                        n_acc[0] += wins;
+                        n_acc[1] += produced - produced0;
+#endif
+                        BZ_STAMP(1);
+                        if (wins) continue;
+                    }
+                }
                 BZ_COUNT(0);
                 const uint64_t bp = P + (uint32_t)lane;
                 const uint32_t d = (uint32_t)(bp >> 5);
@@ -530,6 +676,7 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
                 } else {
                     // the last bits of the input: the reference runs out of data when fewer bits than the
                     // longest code of the tree are left (trees are always full-read, huffman.lisp)
+                    const uint32_t maxlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.maxlen);
                     do {
                         if (endbits - (P + off) < maxlen) { short_input = true; break; }
                         const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)lenv, (int)off);
