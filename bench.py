@@ -126,7 +126,8 @@ def _make_bzip2_streams(args):
     """bzip2 -9 streams of `unit_bytes` each (several 900k blocks per stream)."""
     import bz2
     lo, hi, unit_bytes, seed = args
-    return [bz2.compress(_plain(unit_bytes, seed + i), 9) for i in range(lo, hi)]
+    level = int(os.environ.get("SEMZ_BENCH_BZ_LEVEL", "9"))          # (experiments: smaller blocks)
+    return [bz2.compress(_plain(unit_bytes, seed + i), level) for i in range(lo, hi)]
 
 
 def _make_xz_streams(args):
