@@ -332,9 +332,9 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
     //
     // Wave 1: RLE2 + MTF, 64 queued symbols at a time.  Every symbol is RUNA/RUNB or an MTF index, so the run
     // symbols between two MTF symbols are one run whose bits come straight out of the RUNB ballot; only MTF
-    // symbols are walked one by one.  The first 64 entries of the MTF list live in one VGPR (one entry per
-    // lane): an index below 64 (nearly all of them) is a readlane, a DPP wave shift and a select; the other
-    // entries stay in LDS and are moved there.  The bytes of consecutive MTF symbols collect in one VGPR (lane
+    // symbols are walked one by one.  The MTF list lives in four VGPRs (one entry per lane): an index below 64
+    // (nearly all of them, on text) is a readlane, a DPP wave shift and a select in the first of them; a larger
+    // one shifts whole registers with a carry lane.  The bytes of consecutive MTF symbols collect in one VGPR (lane
     // e = e-th of them) and are stored together in front of the next run or at the end of the batch; a run is
     // stored by all lanes at once (nothing in this kernel reads `pre` back).
     //
