@@ -111,6 +111,8 @@ struct __align__(16) UnitLds {
     TreeMeta lit, dist, clen;
 };
 static_assert(sizeof(UnitLds) <= 10240, "sixteen units per CU");
+static_assert(__builtin_offsetof(UnitLds, lens) % 8 == 0 && sizeof(((UnitLds *)nullptr)->lens) >= 8 * 40 &&
+              8 * 40 * 8 >= ROUND_BYTES + 258, "the resolve step's bitmap of match starts lives in `lens`");
 static_assert(__builtin_offsetof(UnitLds, clen_root) % 8 == 0 &&
               __builtin_offsetof(UnitLds, lit) - __builtin_offsetof(UnitLds, clen_root) >= 512, "64 dummy queue slots fit the table scratch");
 
@@ -806,10 +808,10 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
             // A match whose whole source lies before the round's first byte depends on nothing produced in this
             // round (the round's literals are already in the ring).  All such matches are resolved together with
             // lanes = bytes: an exclusive prefix sum of their lengths lays their bytes out back to back, and for
-            // every 64 of those bytes a lane finds its match (flag scatter through LDS + max-scan), fetches that
-            // match's fields with bpermute and loads its byte -- from the ring, from HBM (older than the ring:
-            // written by this wave, read back through L2) or from the preset dictionary.  Four such 64-byte chunks
-            // are in flight per pass.  The other matches read bytes of this round and follow, in token order.
+            // every 64 of those bytes a lane finds its match (below), takes that match's source and destination
+            // from LDS and loads its byte -- from the ring, from HBM (older than the ring: written by this wave,
+            // read back through L2) or from the preset dictionary.  Four such 64-byte chunks are in flight per
+            // pass.  The other matches read bytes of this round and follow, in token order.
             const bool indep = is_match && tsrel + (int32_t)tlen <= 0;
             const uint32_t plen = indep ? tlen : 0u;
             const uint32_t pincl = wave_scan_add(plen), poff = pincl - plen;
@@ -817,45 +819,70 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
             uint64_t nearm = __builtin_amdgcn_ballot_w64(is_match && !indep);
             uint64_t rawm = __builtin_amdgcn_ballot_w64((tk.x & 3) == T_RAW);
             COUNT(4, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(indep))); COUNT(5, (uint32_t)__builtin_popcountll(nearm));
-            uint32_t carry = 0;                 // queue lane of the match that covers the first byte of the next chunk
-            for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
-                uint32_t gv[4], ov[4], di[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t lo = cb + 64u * c;
-                    gv[c] = 0; ov[c] = 0; di[c] = 0xFFFFFFFFu;
-                    if (lo < PB) {
-                        lds_sync();
-                        L.flags[lane] = 0;
-                        lds_sync();
-                        if (indep && poff - lo < 64u) L.flags[poff - lo] = (uint8_t)(lane + 1);
-                        join_lanes();
-                        lds_sync();
-                        const uint32_t f = L.flags[lane];
-                        const uint32_t t = wave_scan_max(f ? ((lane + 1) << 8) | (f - 1) : 0u);
-                        const uint32_t j = t ? (t & 0xFF) : carry;
-                        carry = (uint32_t)__builtin_amdgcn_readlane((int)j, 63);
-                        const int32_t srel = __builtin_amdgcn_ds_bpermute((int)(4 * j), tsrel);
-                        const uint32_t doff = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * j), (int)tdoff);
-                        const uint32_t po = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4 * j), (int)poff);
-                        const uint32_t k = lo + lane - po;
-                        const bool act = lo + lane < PB;
-                        const int64_t sabs = (int64_t)pos0 + srel + (int64_t)k;
-                        const bool useg = act && sabs >= 0 && sabs < near_lo;
-                        const bool neg = act && sabs < 0;
-                        gv[c] = __hip_atomic_load(useg ? ob + sabs : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ov[c] = L.ring[(uint32_t)((uint64_t)sabs + shift) & RING_MASK];
-                        if (__builtin_amdgcn_ballot_w64(neg)) {             // preset dictionary bytes (zlib FDICT, deflate prefix)
-                            if (neg) ov[c] = prefix_end[sabs];
-                            join_lanes();
-                        }
-                        if (act) di[c] = (((uint32_t)pos0 + doff + k + shift) & RING_MASK) | (useg ? 0x80000000u : 0u);
-                    }
+            if (PB) {
+                // Which match a byte belongs to: the starts of the matches' byte ranges are bits of a bitmap over the
+                // PB bytes (one LDS atomic per match and round), and a byte's match is the r-th of them, r = the
+                // number of starts at or below the byte -- the starts below the chunk, counted as the chunks go
+                // by, plus a popcount of the chunk's 64 bits under the lane's mask.  The matches' fields wait in
+                // LDS in that order, packed into a word: A = source - byte index and B = destination - byte index,
+                // both relative to the round's first byte (A in [-35 k, 0), B within +-2.3 k).  (The first version
+                // scattered lane numbers into 64 flag bytes per chunk, max-scanned them and fetched three fields
+                // by bpermute: 60 instructions and three LDS round trips per chunk where this takes half.)
+                uint32_t *const bitmap = reinterpret_cast<uint32_t *>(L.lens);          // 320 bytes: 2,305 bits at most
+                uint32_t *const packed = reinterpret_cast<uint32_t *>(L.queue);         // (the queue is in registers by now)
+                const uint64_t indepm = __builtin_amdgcn_ballot_w64(indep);
+                const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(indepm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)indepm, 0));
+                lds_sync();
+                if (lane < 40) reinterpret_cast<uint2 *>(bitmap)[lane] = make_uint2(0, 0);
+                join_lanes();
+                lds_sync();
+                if (indep) {
+                    __hip_atomic_fetch_or(&bitmap[poff >> 5], 1u << (poff & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    packed[irank] = ((uint32_t)(tsrel - (int32_t)poff) & 0x3FFFFu) | ((uint32_t)((int32_t)tdoff - (int32_t)poff) << 18);
                 }
+                join_lanes();
+                lds_sync();
+                // the lane's mask of the positions at or below it, as two words
+                const uint32_t le_lo = lane < 32 ? (0xFFFFFFFFu >> (31 - lane)) : 0xFFFFFFFFu;
+                const uint32_t le_hi = lane < 32 ? 0u : (0xFFFFFFFFu >> (63 - lane));
+                // positions relative to the round's first byte, in 32 bits: what lies before the output (history) and
+                // what is still in the ring
+                const int32_t npos = pos0 < 0x7FFFFFFFull ? -(int32_t)pos0 : INT32_MIN;
+                const int32_t nl_rel = (int32_t)(near_lo - (int64_t)pos0);
+                const uint32_t rp0 = (uint32_t)pos0 + shift;
+                const uint8_t *const gbase = ob + pos0;
+                uint32_t before = 0;                // starts in front of the chunk
+                for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
+                    uint32_t gv[4], ov[4], di[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if (di[c] != 0xFFFFFFFFu) L.ring[di[c] & RING_MASK] = (uint8_t)((di[c] >> 31) ? gv[c] : ov[c]);
-                    join_lanes();
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t lo = cb + 64u * c;
+                        gv[c] = 0; ov[c] = 0; di[c] = 0xFFFFFFFFu;
+                        if (lo < PB) {
+                            const uint2 sb = *reinterpret_cast<const uint2 *>(bitmap + (lo >> 5));
+                            const uint32_t r = (uint32_t)__builtin_popcount(sb.x & le_lo) + (uint32_t)__builtin_popcount(sb.y & le_hi);
+                            const uint32_t w = packed[before + r - 1];
+                            before += (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
+                            const uint32_t bidx = lo + lane;                          // the byte's index among the PB bytes
+                            const int32_t srel = ((int32_t)(w << 14) >> 14) + (int32_t)bidx;    // source, relative to pos0: negative
+                            const uint32_t drel = (uint32_t)(((int32_t)w >> 18) + (int32_t)bidx);
+                            const bool act = bidx < PB;
+                            const bool neg = act && srel < npos;
+                            const bool useg = act && !neg && srel < nl_rel;
+                            gv[c] = __hip_atomic_load(useg ? gbase + srel : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ov[c] = L.ring[(rp0 + (uint32_t)srel) & RING_MASK];
+                            if (__builtin_amdgcn_ballot_w64(neg)) {         // preset dictionary bytes (zlib FDICT, deflate prefix)
+                                if (neg) ov[c] = prefix_end[(int64_t)pos0 + srel];
+                                join_lanes();
+                            }
+                            if (act) di[c] = ((rp0 + drel) & RING_MASK) | (useg ? 0x80000000u : 0u);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (di[c] != 0xFFFFFFFFu) L.ring[di[c] & RING_MASK] = (uint8_t)((di[c] >> 31) ? gv[c] : ov[c]);
+                        join_lanes();
+                    }
                 }
             }
             // stored spans straight from the input
