@@ -850,32 +850,48 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 const int32_t npos = pos0 < 0x7FFFFFFFull ? -(int32_t)pos0 : INT32_MIN;
                 const int32_t nl_rel = (int32_t)(near_lo - (int64_t)pos0);
                 const uint32_t rp0 = (uint32_t)pos0 + shift;
-                const uint8_t *const gbase = ob + pos0;
+                // (loads from HBM go through one uniform base and a 32-bit offset; lanes with nothing to fetch
+                // there read a byte that exists: the last flushed one, or the unit's first)
+                constexpr int32_t GBIAS = 1 << 16;
+                const uint8_t *const gbase = reinterpret_cast<const uint8_t *>((uintptr_t)(ob + pos0) - (uintptr_t)GBIAS);
+                const int32_t safe_rel = near_lo > 0 ? nl_rel - 1 : npos;
+                const bool may_neg = prefix_amount != 0 && pos0 < 40000;        // sources in the preset history at all?
                 uint32_t before = 0;                // starts in front of the chunk
                 for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
-                    uint32_t gv[4], ov[4], di[4];
+                    // A pass of four chunks without a branch (bits beyond PB are zero, lanes beyond PB are masked at
+                    // the end), in three steps so that the LDS round trips of the four chunks overlap: the counts,
+                    // the matches' words, the bytes.
+                    uint32_t r[4], w[4], gv[4], ov[4], di[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const uint32_t lo = cb + 64u * c;
-                        gv[c] = 0; ov[c] = 0; di[c] = 0xFFFFFFFFu;
-                        if (lo < PB) {
-                            const uint2 sb = *reinterpret_cast<const uint2 *>(bitmap + (lo >> 5));
-                            const uint32_t r = (uint32_t)__builtin_popcount(sb.x & le_lo) + (uint32_t)__builtin_popcount(sb.y & le_hi);
-                            const uint32_t w = packed[before + r - 1];
-                            before += (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
-                            const uint32_t bidx = lo + lane;                          // the byte's index among the PB bytes
-                            const int32_t srel = ((int32_t)(w << 14) >> 14) + (int32_t)bidx;    // source, relative to pos0: negative
-                            const uint32_t drel = (uint32_t)(((int32_t)w >> 18) + (int32_t)bidx);
-                            const bool act = bidx < PB;
-                            const bool neg = act && srel < npos;
-                            const bool useg = act && !neg && srel < nl_rel;
-                            gv[c] = __hip_atomic_load(useg ? gbase + srel : safe_byte, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            ov[c] = L.ring[(rp0 + (uint32_t)srel) & RING_MASK];
-                            if (__builtin_amdgcn_ballot_w64(neg)) {         // preset dictionary bytes (zlib FDICT, deflate prefix)
-                                if (neg) ov[c] = prefix_end[(int64_t)pos0 + srel];
-                                join_lanes();
-                            }
-                            if (act) di[c] = ((rp0 + drel) & RING_MASK) | (useg ? 0x80000000u : 0u);
+                        const uint2 sb = *reinterpret_cast<const uint2 *>(bitmap + ((cb + 64u * c) >> 5));
+                        r[c] = (uint32_t)__builtin_popcount(sb.x & le_lo) + (uint32_t)__builtin_popcount(sb.y & le_hi);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        w[c] = packed[(before + r[c] - 1) & 63];
+                        before += (uint32_t)__builtin_amdgcn_readlane((int)r[c], 63);
+                    }
+                    uint64_t negm = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t bidx = cb + 64u * c + lane;                   // the byte's index among the PB bytes
+                        const int32_t srel = ((int32_t)(w[c] << 14) >> 14) + (int32_t)bidx;    // source, relative to pos0: negative
+                        const uint32_t drel = (uint32_t)(((int32_t)w[c] >> 18) + (int32_t)bidx);
+                        const bool act = bidx < PB;
+                        const bool useg = act && srel >= npos && srel < nl_rel;
+                        gv[c] = __hip_atomic_load(gbase + (uint32_t)((useg ? srel : safe_rel) + GBIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ov[c] = L.ring[(rp0 + (uint32_t)srel) & RING_MASK];
+                        di[c] = act ? ((rp0 + drel) & RING_MASK) | (useg ? 0x80000000u : 0u) : 0xFFFFFFFFu;
+                        if (may_neg) negm |= __builtin_amdgcn_ballot_w64(act && srel < npos);
+                    }
+                    if (may_neg && negm) {                  // preset dictionary bytes (zlib FDICT, deflate prefix)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const uint32_t bidx = cb + 64u * c + lane;
+                            const int32_t srel = ((int32_t)(w[c] << 14) >> 14) + (int32_t)bidx;
+                            if (bidx < PB && srel < npos) ov[c] = prefix_end[(int64_t)pos0 + srel];
+                            join_lanes();
                         }
                     }
 #pragma unroll
