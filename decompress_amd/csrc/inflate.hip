@@ -855,6 +855,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 constexpr int32_t GBIAS = 1 << 16;
                 const uint8_t *const gbase = reinterpret_cast<const uint8_t *>((uintptr_t)(ob + pos0) - (uintptr_t)GBIAS);
                 const int32_t safe_rel = near_lo > 0 ? nl_rel - 1 : npos;
+                const bool far_possible = near_lo > 0;
                 const bool may_neg = prefix_amount != 0 && pos0 < 40000;        // sources in the preset history at all?
                 uint32_t before = 0;                // starts in front of the chunk
                 for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
@@ -880,7 +881,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         const uint32_t drel = (uint32_t)(((int32_t)w[c] >> 18) + (int32_t)bidx);
                         const bool act = bidx < PB;
                         const bool useg = act && srel >= npos && srel < nl_rel;
-                        gv[c] = __hip_atomic_load(gbase + (uint32_t)((useg ? srel : safe_rel) + GBIAS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // (while the unit's output still fits the ring nothing is older than the ring: no loads at
+                        // all -- a 4 KiB record never makes one, and a load that nobody needs is still waited for)
+                        gv[c] = far_possible ? __hip_atomic_load(gbase + (uint32_t)((useg ? srel : safe_rel) + GBIAS), __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT)
+                                             : 0u;
                         ov[c] = L.ring[(rp0 + (uint32_t)srel) & RING_MASK];
                         di[c] = act ? ((rp0 + drel) & RING_MASK) | (useg ? 0x80000000u : 0u) : 0xFFFFFFFFu;
                         if (may_neg) negm |= __builtin_amdgcn_ballot_w64(act && srel < npos);
