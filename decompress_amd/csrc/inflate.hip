@@ -919,6 +919,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     if (k0 + lane < len) L.ring[(p + k0 + lane) & RING_MASK] = s[k0 + lane];
             }
             // near matches in token order; LDS operations of one wave execute in order
+            // (what the round has in front of it, saturated: a source can only begin in the preset history while this is small)
+            const uint32_t hist32 = pos0 < 0x7FFFFFFFull ? (uint32_t)pos0 : 0x7FFFFFFFu;
             while (nearm) {
                 const uint32_t j = (uint32_t)__builtin_ctzll(nearm);
                 nearm &= nearm - 1;
@@ -927,6 +929,13 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 const uint32_t len = (tx >> 2) & 0x3FFF;
                 const uint32_t p = (uint32_t)(pos0 + (tx >> 16)) + shift;     // ring index of the destination
                 const uint32_t src = p - dist;
+                // the usual one first: at most 64 bytes, at least as far back as it is long, the source in the output
+                if (__builtin_expect(len <= 64 && dist >= len && dist <= hist32 + (tx >> 16), 1)) {
+                    const uint32_t v = L.ring[(src + lane) & RING_MASK];
+                    if (lane < len) L.ring[(p + lane) & RING_MASK] = (uint8_t)v;
+                    join_lanes();
+                    continue;
+                }
                 const int64_t sabs0 = (int64_t)(pos0 + (tx >> 16)) - (int64_t)dist;
                 if (sabs0 < 0) {
                     // the source starts in the preset history and runs on into this round's output: byte k repeats
