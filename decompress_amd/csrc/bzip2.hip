@@ -184,6 +184,16 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Lists of up to six trees, one per nibble: the list `a` rearranged as `b` says (nibble j of the result is the
+// nibble of `a` that nibble j of `b` names).  Rearranging by b and then by c is rearranging by bz_list_after(b, c).
+__device__ __forceinline__ uint32_t bz_list_after(uint32_t a, uint32_t b)
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) r |= ((a >> (4 * ((b >> (4 * j)) & 7))) & 15) << (4 * j);
+    return r;
+}
+
 // MSB-first bit reader (msb-bit-reader, bits.lisp:121).  Every lane of the
 // wave holds the same state.  The input is staged cooperatively (64 lanes x 16
 // bytes) in aligned 1 KiB pieces into a 2 KiB LDS ring, so the piece before the
@@ -412,8 +422,96 @@ __global__ __launch_bounds__(128) void bz_decode_kernel(const uint8_t *in, uint6
             // read-bzip2-selectors (bzip2.lisp:302-311): codes 0,10,110,1110,11110,111110,111111, then MTF
             {
                 uint32_t stack = 0x543210u;                 // nibble j = tree at MTF position j
-                uint32_t packed = 0;                        // eight selectors per LDS word
-                for (uint32_t i = 0; i < nsel; i++) {
+                uint32_t ndone = 0;
+                // Every code of a tree the block has ends in a 0, so selector k ends at the k-th 0 bit and its
+                // MTF index is the number of ones in front of it: 2048 bits at a time, lane l takes the zeros of
+                // bits [32 l, 32 l + 32).  Moving to the front rearranges the list, and rearrangements compose:
+                // each lane walks its own zeros from the list 0..5 (pass 1: which place of the list it was handed
+                // each selector takes, and the lane's whole rearrangement), a scan over the lanes gives each lane
+                // the list it is handed, and a second, short walk looks the trees up in it.  Anything that may
+                // fail (a run of ones that is no tree of this block, the end of the input within reach) is left
+                // to the loop below, which starts where the last good piece ended.
+                uint8_t *stg = reinterpret_cast<uint8_t *>(L.tree);    // (the trees are built after this)
+                static_assert(sizeof(L.tree) >= 2048 + 8, "selector staging");
+                uint64_t B = br.bitpos();
+                const uint64_t B0 = B;
+                while (ndone < nsel) {
+                    if (8 * br.limit < B + 2048 + 64 || (B >> 5) * 4 < br.in_lo) break;
+                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(br.in_v0) + (B >> 5);
+                    const uint32_t wa = __builtin_bswap32(w32[lane]), wb = __builtin_bswap32(w32[lane + 1]);
+                    const uint32_t z = ~(uint32_t)((((((uint64_t)wa << 32) | wb) << ((uint32_t)B & 31))) >> 32);
+                    const uint32_t n = (uint32_t)__builtin_popcount(z);
+                    const uint32_t incl = wave_scan_add(n), basel = incl - n;
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (total == 0) break;
+                    const uint32_t used = total < nsel - ndone ? total : nsel - ndone;
+                    const uint32_t neff = basel < used ? (n < used - basel ? n : used - basel) : 0u;
+                    // ones at the end of the lane below: the front of this lane's first selector
+                    const uint32_t zprev = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)z, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    uint32_t c = zprev ? (uint32_t)__builtin_ctz(zprev) : 32u;
+                    uint32_t zs = z, S = 0x543210u;
+                    bool bad = false;
+                    const uint32_t off = (ndone & 7) + basel;
+                    for (uint32_t it = 0; __builtin_amdgcn_ballot_w64(it < neff); it++) {
+                        const bool act = it < neff;
+                        const uint32_t tz = zs ? (uint32_t)__builtin_clz(zs) : 0u;
+                        uint32_t idx = tz + c;
+                        c = 0;
+                        zs = (zs << tz) << 1;
+                        bad |= act && idx >= ntrees;
+                        if (idx > 5) idx = 5;
+                        const uint32_t sh = 4 * idx, val = (S >> sh) & 15;
+                        const uint32_t S2 = (S & ~((1u << (sh + 4)) - 1)) | ((S & ((1u << sh) - 1)) << 4) | val;
+                        if (act) {
+                            S = S2;
+                            stg[off + it] = (uint8_t)val;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(bad)) break;
+                    uint32_t X = S;
+#pragma unroll
+                    for (int d = 1; d < 64; d *= 2) {
+                        const uint32_t below = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane - d), (int)X);
+                        if (lane >= d) X = bz_list_after(below, X);
+                    }
+                    const uint32_t xbelow = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (lane - 1), (int)X);
+                    const uint32_t handed = lane ? bz_list_after(stack, xbelow) : stack;
+                    stack = bz_list_after(stack, (uint32_t)__builtin_amdgcn_readlane((int)X, 63));
+                    for (uint32_t it = 0; __builtin_amdgcn_ballot_w64(it < neff); it++)
+                        if (it < neff) stg[off + it] = (uint8_t)((handed >> (4 * stg[off + it])) & 15);
+                    lds_sync();
+                    const uint32_t cnt = (ndone & 7) + used;
+                    const bool last = ndone + used == nsel;
+                    const uint32_t nwords = last ? (cnt + 7) >> 3 : cnt >> 3;
+                    for (uint32_t m = (uint32_t)lane; m < nwords; m += 64) {
+                        uint64_t x = *reinterpret_cast<const uint64_t *>(stg + 8 * m);
+                        if (cnt - 8 * m < 8) x &= (1ull << (8 * (cnt - 8 * m))) - 1;
+                        uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+                        lo = (lo | (lo >> 4)) & 0x00FF00FFu; lo = (lo | (lo >> 8)) & 0xFFFFu;
+                        hi = (hi | (hi >> 4)) & 0x00FF00FFu; hi = (hi | (hi >> 8)) & 0xFFFFu;
+                        selg[(ndone >> 3) + m] = lo | (hi << 16);
+                    }
+                    lds_sync();
+                    const uint32_t rem = last ? 0u : cnt & 7;
+                    const uint8_t keep = (uint32_t)lane < rem ? stg[(cnt & ~7u) + lane] : (uint8_t)0;
+                    lds_sync();
+                    if ((uint32_t)lane < rem) stg[lane] = keep;
+                    lds_sync();
+                    // the last 0 this piece used
+                    const uint32_t src = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(basel < used && used <= incl));
+                    uint32_t zz = (uint32_t)__builtin_amdgcn_readlane((int)z, (int)src);
+                    const uint32_t skip = used - (uint32_t)__builtin_amdgcn_readlane((int)basel, (int)src) - 1;
+                    for (uint32_t i = 0; i < skip; i++) zz &= ~(0x80000000u >> __builtin_clz(zz));
+                    B += 32 * src + (uint32_t)__builtin_clz(zz) + 1;
+                    ndone += used;
+                }
+                uint32_t packed = 0;                        // eight selectors per word
+                if (B != B0) {
+                    br.init(br.in_v0, br.ring, br.in_lo, br.limit, B >> 3, (uint32_t)(B & 7));
+                    for (uint32_t i = 0; i < (ndone & 7) && ndone < nsel; i++)
+                        packed |= (uint32_t)__builtin_amdgcn_readfirstlane((int)stg[i]) << (4 * i);
+                }
+                for (uint32_t i = ndone; i < nsel; i++) {
                     br.refill();
                     if (br.short_of(6)) BZ_FAIL(SEMZ_EOF, 0);
                     uint32_t six = br.peek(6);

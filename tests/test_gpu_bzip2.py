@@ -111,6 +111,39 @@ def test_truncated_block(engine):
         assert res[0].status == er.status == 1, (cut, res[0].status, er.status)
 
 
+def test_faults_in_the_selector_section(engine):
+    """The selectors of a full block (about 18000, some 5 KB behind the block header) are taken 2048 bits at a time by
+    the whole wave; a piece that holds a run of ones that is no tree, or that reaches the end of the input, goes back to
+    the loop that takes them one by one.  Single bit flips and cuts all over that section of a 900 k block, each against
+    the oracle: status and detail, and the bytes where the block still decodes."""
+    random.seed(23)
+    d = corpus.text(900_000, seed=23)
+    base = bz2.compress(d, 9)
+    u = _lib.Unit(in_off=4, in_limit=len(base), out_off=_lib.OUT_AUTO, kind=_lib.UNIT_BZIP2_BLOCK, param0=9)
+    seen = set()
+    for t in range(48):
+        b = bytearray(base)
+        pos = random.randrange(60, 5200)
+        b[pos] ^= 1 << random.randrange(8)
+        data = bytes(b)
+        out, res = engine.decode_batch(data, [u], 1 << 20)
+        er, eo = oracle.bzip2_block(data, 32, 9, cap=1 << 20)
+        assert res[0].status == er.status, (t, pos, res[0].status, er.status)
+        seen.add(er.status)
+        if er.status == 0:
+            assert out.raw[:res[0].out_len] == eo
+        else:
+            assert res[0].detail == er.detail, (t, pos, res[0].status, res[0].detail, er.detail)
+    assert len(seen) >= 2, seen                                   # (not all the same failure)
+    for cut in (80, 300, 311, 1000, 2500, 4000, 5000, 5500, 7000):
+        data = base[:cut]
+        uu = _lib.Unit(in_off=4, in_limit=len(data), out_off=_lib.OUT_AUTO, kind=_lib.UNIT_BZIP2_BLOCK, param0=9)
+        _, res = engine.decode_batch(data, [uu], 1 << 20)
+        er, _ = oracle.bzip2_block(data, 32, 9, cap=1 << 20)
+        assert res[0].status == er.status, (cut, res[0].status, er.status)
+        assert res[0].detail == er.detail, (cut, res[0].detail, er.detail)
+
+
 def test_out_cap_and_explicit_offsets(engine):
     d = corpus.text(250000, seed=6)
     data = bz2.compress(d, 1)
