@@ -1024,6 +1024,62 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     int i = 0;
                     uint32_t prev = 0;
                     uint32_t x = 0, have = 0;                // the next `have` bits of the input from P on
+                    // Windows first, as for the tokens: lane l decodes the code that would start at bit P + l, the
+                    // chain of real starts is followed with readlane, a prefix sum over the run lengths places every
+                    // code, and a repeat (16) takes the value of the nearest code below it that is not one.  Runs of
+                    // zeros (17, 18) store nothing: the array starts out zeroed.  A window that holds any of the
+                    // reference's failures, or comes near the end of the input, is left to the loop below.
+                    for (uint32_t k = lane; k < sizeof L.lens; k += 64) L.lens[k] = 0;
+                    join_lanes();
+                    lds_sync();
+                    while (i < total && endbits - P >= 64 + 14 + 64) {
+                        ensure_staged();
+                        const uint32_t bp = (uint32_t)P + lane;
+                        const uint32_t *wp = ring32 + ((bp >> 5) & (IN_RING / 4 - 1));
+                        const uint32_t wx = __builtin_amdgcn_alignbit(wp[1], wp[0], bp & 31);
+                        const uint32_t ce = L.clen_root[wx & ((1u << CLEN_ROOT_BITS) - 1)];
+                        const uint32_t cl = ce & 7, sym = ce >> 3;
+                        const uint32_t xb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+                        const uint32_t n = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + __builtin_amdgcn_ubfe(wx, cl, xb);
+                        const uint32_t tb = (cl ? cl : 1u) + xb;          // (a complete tree has no empty entry; the chain must end all the same)
+                        // (the chain as in the token windows: `offb` biased by 2^32 - 64, the add carries out at the end)
+                        uint64_t starts = 0;
+                        uint32_t offb = 0u - 64u, tlen;
+#define CHAIN_STEP "v_readlane_b32 %[t], %[tb], %[off]\n\ts_bitset1_b64 %[m], %[off]\n\ts_add_u32 %[off], %[off], %[t]\n\t"
+                        asm volatile("s_nop 0\n"
+                                     "1:\n\t"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
+                                     CHAIN_STEP "s_cbranch_scc0 1b\n"
+                                     "2:"
+                                     : [m] "+s"(starts), [off] "+s"(offb), [t] "=&s"(tlen)
+                                     : [tb] "v"(tb)
+                                     : "scc");
+#undef CHAIN_STEP
+                        const bool isstart = lane_of(starts);
+                        const uint32_t nm = isstart ? n : 0u;
+                        const uint32_t posl = (uint32_t)i + wave_scan_add(nm) - nm;
+                        const uint64_t um = __builtin_amdgcn_ballot_w64(isstart && posl < (uint32_t)total);
+                        const bool usable = lane_of(um);
+                        if (__builtin_amdgcn_ballot_w64(usable && (cl == 0 || posl + n > (uint32_t)total || (sym == 16 && posl == 0)))) break;
+                        const uint64_t m16 = __builtin_amdgcn_ballot_w64(usable && sym == 16);
+                        const uint64_t lower = um & ~m16 & ((1ull << lane) - 1);
+                        const uint32_t own = sym < 16 ? sym : 0u;
+                        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (63 - (int)__builtin_clzll(lower | 1)), (int)own);
+                        const uint32_t v = sym == 16 ? (lower ? got : prev) : own;
+                        if (usable && sym < 16) L.lens[posl] = (uint8_t)sym;
+                        join_lanes();
+                        if (m16) {
+                            for (uint32_t k = 0; k < 6; k++)
+                                if (lane_of(m16) && k < n) L.lens[posl + k] = (uint8_t)v;
+                            join_lanes();
+                        }
+                        const int last = 63 - (int)__builtin_clzll(um);
+                        prev = (uint32_t)__builtin_amdgcn_readlane((int)v, last);
+                        i = __builtin_amdgcn_readlane((int)(posl + n), last);
+                        P += (uint32_t)last + (uint32_t)__builtin_amdgcn_readlane((int)tb, last);
+                    }
                     while (i < total) {
                         if (have < 14) {                     // a code takes at most 7 bits and 7 extra bits
                             ensure_staged();
