@@ -138,6 +138,30 @@ def test_truncated_and_corrupt(engine, group):
     check_items(engine, items, group)
 
 
+def test_faults_in_the_dynamic_header(engine):
+    """The code lengths of a dynamic block are taken in 64-bit windows by the whole wave; a window that holds one of
+    the reference's failures (a repeat with nothing before it, a run beyond the last code, an incomplete tree
+    afterwards) or comes near the end of the input goes back to the loop that takes them one by one.  Every bit of the
+    first 96 bytes of three raw streams flipped in turn, and cuts all over the header, each against the oracle."""
+    seen = set()
+    for seed, gen, n in ((1, corpus.text, 40000), (2, corpus.mixed, 9000), (3, corpus.repetitive, 30000)):
+        d = gen(n, seed=seed)
+        blob = compress(0, d, 6)
+        items = []
+        for byte in range(min(96, len(blob))):
+            for bit in range(8):
+                b = bytearray(blob)
+                b[byte] ^= 1 << bit
+                items.append((0, bytes(b), len(d) + 600))
+        for cut in range(2, min(140, len(blob)), 3):
+            items.append((0, blob[:cut], len(d) + 8))
+        for i in range(0, len(items), 64):
+            check_items(engine, items[i:i + 64], 64)
+        for it in items[::7]:
+            seen.add(oracle_unit(0, it[1], it[2])[0].status)
+    assert len(seen) >= 4, seen                                         # (several different failures among them)
+
+
 def test_trailer_mismatches(engine):
     d = corpus.text(5000, seed=5)
     g = bytearray(compress(2, d))
