@@ -491,6 +491,9 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
     auto short_of = [&](uint32_t n) -> bool { return endbits - P < (uint64_t)n; };
 
     STAMP_DECL
+    // (a block of assembler in the resolve step adds no base to its ring indices: the ring is this kernel's first LDS object)
+    const bool ring_at_0 = (uint32_t)__builtin_amdgcn_readfirstlane(
+                               (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)L.ring) == 0;
     // ---- main loop: one round per iteration ----
     for (;;) {
         // (semz_device.h: the units of a SIMD end together.  A record of a few kilobytes never asks)
@@ -922,6 +925,49 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
             // (what the round has in front of it, saturated: a source can only begin in the preset history while this is small)
             const uint32_t hist32 = pos0 < 0x7FFFFFFFull ? (uint32_t)pos0 : 0x7FFFFFFFu;
             while (nearm) {
+                if (ring_at_0) {
+                    // The usual ones (at most 64 bytes, at least as far back as long, the source in the output) one
+                    // after the other without leaving the block: 26 instructions and one taken branch a match where
+                    // the compiler's version of the same path has 45 and four, each condition kept as a flag
+                    // register first.  Leaves in front of the first match that is not of this kind.
+                    static_assert(RING_MASK == 0xfff, "the ring mask is written out in the block below");
+                    uint64_t ex;
+                    uint32_t sj, stx, sd, slen, sdoff, st0, sp, va, vb, vv;
+                    asm volatile("s_mov_b64 %[ex], exec\n"
+                                 "1:\n\t"
+                                 "s_ff1_i32_b64 %[j], %[nm]\n\t"
+                                 "v_readlane_b32 %[tx], %[vx], %[j]\n\t"
+                                 "v_readlane_b32 %[d], %[vy], %[j]\n\t"
+                                 "s_bfe_u32 %[len], %[tx], 0xe0002\n\t"
+                                 "s_lshr_b32 %[doff], %[tx], 16\n\t"
+                                 "s_cmp_gt_u32 %[len], 64\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_cmp_lt_u32 %[d], %[len]\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_add_u32 %[t], %[hist], %[doff]\n\t"
+                                 "s_cmp_gt_u32 %[d], %[t]\n\t"
+                                 "s_cbranch_scc1 2f\n\t"
+                                 "s_add_u32 %[p], %[base], %[doff]\n\t"
+                                 "s_sub_u32 %[t], %[p], %[d]\n\t"
+                                 "v_add_u32_e32 %[a], %[t], %[lane]\n\t"
+                                 "v_and_b32_e32 %[a], 0xfff, %[a]\n\t"
+                                 "ds_read_u8 %[v], %[a]\n\t"
+                                 "v_add_u32_e32 %[b], %[p], %[lane]\n\t"
+                                 "v_and_b32_e32 %[b], 0xfff, %[b]\n\t"
+                                 "s_bitset0_b64 %[nm], %[j]\n\t"
+                                 "v_cmpx_gt_u32_e32 vcc, %[len], %[lane]\n\t"
+                                 "s_waitcnt lgkmcnt(0)\n\t"
+                                 "ds_write_b8 %[b], %[v]\n\t"
+                                 "s_mov_b64 exec, %[ex]\n\t"
+                                 "s_cmp_lg_u64 %[nm], 0\n\t"
+                                 "s_cbranch_scc1 1b\n"
+                                 "2:"
+                                 : [nm] "+s"(nearm), [ex] "=&s"(ex), [j] "=&s"(sj), [tx] "=&s"(stx), [d] "=&s"(sd), [len] "=&s"(slen),
+                                   [doff] "=&s"(sdoff), [t] "=&s"(st0), [p] "=&s"(sp), [a] "=&v"(va), [b] "=&v"(vb), [v] "=&v"(vv)
+                                 : [vx] "v"(tk.x), [vy] "v"(tk.y), [lane] "v"(lane), [hist] "s"(hist32), [base] "s"((uint32_t)pos0 + shift)
+                                 : "scc", "vcc", "memory");
+                    if (!nearm) break;
+                }
                 const uint32_t j = (uint32_t)__builtin_ctzll(nearm);
                 nearm &= nearm - 1;
                 const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)tk.x, (int)j);
