@@ -548,37 +548,67 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         length = 3 + (e >> 8) + __builtin_amdgcn_ubfe(lo, cl, lx);
                         const uint32_t o2 = cl + lx;                           // <= 20
                         const uint32_t y = __builtin_amdgcn_alignbit(hi, lo, o2);
-                        const uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
-                        const uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
-                        distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
+                        uint32_t dd = L.dist_root[y & ((1u << DIST_ROOT_BITS) - 1)];
                         // Lane predicates are kept as 64-bit masks in scalar registers and combined there; lane_of() turns
                         // a mask back into the predicate of a select or a branch without an instruction.
                         litmask = __builtin_amdgcn_ballot_w64((e & LIT_FLAG) != 0);
-                        // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
-                        stopmask = __builtin_amdgcn_ballot_w64(cl == 0) | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
+                        const uint64_t litstop = __builtin_amdgcn_ballot_w64(cl == 0);
                         const bool islit = lane_of(litmask);
-                        const uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
+                        mask = 0;
+                        uint32_t offb = 0u - 64u, tlen;
+                        uint32_t dl = dd & 15, dx = (dd >> 4) & 15;
+                        // tokens the scalar step has to look at have a zero root entry: long codes, block end, invalid codes
+                        stopmask = litstop | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
+                        uint32_t tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
                         // the chain of token starts inside the window
                         // The chain is four instructions per token, written out because the compiler has no way to branch
                         // on the carry of a scalar add: `off` runs biased by 2^32 - 64 (v_readlane and s_bitset1_b64 only
                         // look at its low six bits), so the add carries out exactly when the chain leaves the window.
                         // The s_nop is the wait state gfx950 wants between the VALU write of tbits and a v_readlane of it.
-                        mask = 0;
-                        uint32_t offb = 0u - 64u, tlen;
                         // (four steps per pass: a taken branch costs three instructions' time, DESIGN.md 3.0, and a window
                         // holds five tokens or so)
 #define CHAIN_STEP "v_readlane_b32 %[t], %[tb], %[off]\n\ts_bitset1_b64 %[m], %[off]\n\ts_add_u32 %[off], %[off], %[t]\n\t"
-                        asm volatile("s_nop 0\n"
-                                     "1:\n\t"
-                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
-                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
-                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"
-                                     CHAIN_STEP "s_cbranch_scc0 1b\n"
-                                     "2:"
-                                     : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen)
-                                     : [tb] "v"(tbits)
-                                     : "scc");
+#define CHAIN()                                                                          \
+                        asm volatile("s_nop 0\n"                                         \
+                                     "1:\n\t"                                            \
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"                  \
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"                  \
+                                     CHAIN_STEP "s_cbranch_scc1 2f\n\t"                  \
+                                     CHAIN_STEP "s_cbranch_scc0 1b\n"                    \
+                                     "2:"                                                \
+                                     : [m] "+s"(mask), [off] "+s"(offb), [t] "=&s"(tlen) \
+                                     : [tb] "v"(tbits)                                   \
+                                     : "scc")
+                        CHAIN();
+                        // The chain has stopped at a match whose distance code is longer than the root index (one
+                        // token in 180 on text; a window cut there, the scalar step and the way back into this loop
+                        // cost several windows' time): the code is searched here, lane l trying length l, its entry
+                        // takes the lane's place and the chain goes on from that lane.  Anything else the scalar
+                        // step has to look at stays a stop.
+                        uint64_t hit = mask & stopmask & ~litstop;
+                        if (__builtin_expect(hit != 0, 0)) {
+                            do {
+                                const uint32_t c = 63u - (uint32_t)__builtin_clzll(hit);
+                                const uint32_t v15 = __brev((uint32_t)__builtin_amdgcn_readlane((int)y, (int)c)) >> 17;
+                                const uint32_t lim = L.dist.limit[lane & 15];
+                                const uint64_t found = __builtin_amdgcn_ballot_w64(lane >= 1 && lane <= 15 && v15 < lim);
+                                if (!found) break;
+                                const uint32_t fl = (uint32_t)__builtin_ctzll(found);
+                                const uint32_t idx = uni((uint32_t)L.dist.offs[fl]) + (v15 >> (15 - fl)) - uni((uint32_t)L.dist.first[fl]);
+                                const uint32_t ddc = dist_root_entry(uni((uint32_t)L.dist_sorted[idx & 31]), fl);
+                                if (ddc == 0) break;                           // (30, 31: the scalar step reports them)
+                                dd = lane == c ? ddc : dd;
+                                dl = dd & 15; dx = (dd >> 4) & 15;
+                                stopmask = litstop | (__builtin_amdgcn_ballot_w64(dl == 0) & ~litmask);
+                                tbits = lane_of(stopmask) ? 64u : (islit ? cl : o2 + dl + dx);
+                                offb = c - 64u;
+                                CHAIN();
+                                hit = mask & stopmask & ~litstop;
+                            } while (hit);
+                        }
+#undef CHAIN
 #undef CHAIN_STEP
+                        distance = 1 + (((dd >> 8) & 3) << dx) + __builtin_amdgcn_ubfe(y, dl, dx);
                         off = offb + 64u;
                         matchmask = mask & ~(stopmask | litmask);
                         // (a token of the chain that the scalar step has to take counts as more bytes than a round holds:
@@ -673,6 +703,8 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         uint32_t v15 = __brev(x) >> 17, idx = 0;
                         cl = canon_find(L.lit, v15, 1, 15, idx);
                         e = lit_entry(uni((uint32_t)L.lit_sorted[idx]), cl);
+                        COUNT(6, 1);
+                        if (e & LIT_FLAG) COUNT(7, 1);
                     }
                     if (short_of(lit_full ? (uint32_t)lit_max : cl)) FAIL(SEMZ_EOF, 0)
                     P += cl;

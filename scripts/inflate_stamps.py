@@ -5,7 +5,7 @@ import ctypes as C
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SEMZ_LIB"] = os.path.join(ROOT, "decompress_amd", "libsemz_gpu_stamps.so")
+os.environ["SEMZ_LIB"] = os.environ.get("SEMZ_STAMPS_LIB") or os.path.join(ROOT, "decompress_amd", "libsemz_gpu_stamps.so")
 sys.path.insert(0, ROOT)
 sys.argv = [sys.argv[0]] + (sys.argv[1:] or ["--steps", "1", "--warmup", "0", "--no-cpu"])
 import bench
@@ -23,4 +23,5 @@ for i, n in enumerate(names):
 win, tok, careful, rounds, far, near = (st[6 + i] / units for i in range(6))
 print(f"per unit: windows {win:.0f} window tokens {tok:.0f} ({tok / max(1, win):.2f} per window) scalar steps {careful:.0f} rounds {rounds:.0f} "
       f"matches resolved together (source in front of the round) {far:.0f}, one after the other (source inside the round) {near:.0f}")
+print(f"scalar steps on a literal/length code beyond the root table: {st[12] / units:.0f} per unit, literals among them {st[13] / units:.0f}")
 print(f"ticks per token: total {tot / units / max(1, tok + careful):.0f}  decode only {st[0] / units / max(1, tok + careful):.0f}")
