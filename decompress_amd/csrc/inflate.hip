@@ -41,6 +41,7 @@
 // table plus a canonical (first-code / sorted-symbol) description used for
 // codes longer than the root and for the table fill.
 #include "semz_device.h"
+#include <type_traits>
 
 #ifdef SEMZ_STAMPS
 // diagnostic build only (make STAMPS=1): per-phase shader-clock totals summed over all units
@@ -893,24 +894,26 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 const bool far_possible = near_lo > 0;
                 const bool may_neg = prefix_amount != 0 && pos0 < 40000;        // sources in the preset history at all?
                 uint32_t before = 0;                // starts in front of the chunk
-                for (uint32_t cb = 0; cb < PB; cb = uni(cb + 256)) {
+                // (a pass of NC chunks, NC = 4, 2 or 1: the last pass of a round is as wide as what is left)
+                auto pass = [&](const uint32_t cb, auto nc_tag) {
+                    constexpr int NC = decltype(nc_tag)::value;
                     // A pass of four chunks without a branch (bits beyond PB are zero, lanes beyond PB are masked at
                     // the end), in three steps so that the LDS round trips of the four chunks overlap: the counts,
                     // the matches' words, the bytes.
-                    uint32_t r[4], w[4], gv[4], ov[4], di[4];
+                    uint32_t r[NC], w[NC], gv[NC], ov[NC], di[NC];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NC; c++) {
                         const uint2 sb = *reinterpret_cast<const uint2 *>(bitmap + ((cb + 64u * c) >> 5));
                         r[c] = (uint32_t)__builtin_popcount(sb.x & le_lo) + (uint32_t)__builtin_popcount(sb.y & le_hi);
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NC; c++) {
                         w[c] = packed[(before + r[c] - 1) & 63];
                         before += (uint32_t)__builtin_amdgcn_readlane((int)r[c], 63);
                     }
                     uint64_t negm = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NC; c++) {
                         const uint32_t bidx = cb + 64u * c + lane;                   // the byte's index among the PB bytes
                         const int32_t srel = ((int32_t)(w[c] << 14) >> 14) + (int32_t)bidx;    // source, relative to pos0: negative
                         const uint32_t drel = (uint32_t)(((int32_t)w[c] >> 18) + (int32_t)bidx);
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     }
                     if (may_neg && negm) {                  // preset dictionary bytes (zlib FDICT, deflate prefix)
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
+                        for (int c = 0; c < NC; c++) {
                             const uint32_t bidx = cb + 64u * c + lane;
                             const int32_t srel = ((int32_t)(w[c] << 14) >> 14) + (int32_t)bidx;
                             if (bidx < PB && srel < npos) ov[c] = prefix_end[(int64_t)pos0 + srel];
@@ -935,10 +938,16 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NC; c++) {
                         if (di[c] != 0xFFFFFFFFu) L.ring[di[c] & RING_MASK] = (uint8_t)((di[c] >> 31) ? gv[c] : ov[c]);
                         join_lanes();
                     }
+                };
+                for (uint32_t cb = 0; cb < PB;) {
+                    const uint32_t left = PB - cb;
+                    if (left > 128) { pass(cb, std::integral_constant<int, 4>{}); cb = uni(cb + 256); }
+                    else if (left > 64) { pass(cb, std::integral_constant<int, 2>{}); cb = uni(cb + 128); }
+                    else { pass(cb, std::integral_constant<int, 1>{}); cb = uni(cb + 64); }
                 }
             }
             // stored spans straight from the input
