@@ -523,9 +523,12 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     //   c_tok  queue slots left after this window, minus one      c_byte  round bytes left, minus one
                     //   c_left bits to the end of the input, minus 64 + TOKEN_BITS   c_stg  staged bits ahead, minus 256
                     // `gate` has the sign bit set when windows cannot be kept whole at all in this round.
-                    int32_t c_tok = (int32_t)((uint32_t)QCAP - 1 - ntok), c_byte = (int32_t)((uint32_t)ROUND_BYTES - 1 - rbytes);
+                    // (the round's byte limit is what the output still has room for when that is less: a 4 KiB record's last
+                    // thousand bytes, which went through the cut path window by window, 85 windows of a record's 203)
+                    const uint32_t lim = room < (uint32_t)ROUND_BYTES ? room : (uint32_t)ROUND_BYTES;
+                    int32_t c_tok = (int32_t)((uint32_t)QCAP - 1 - ntok), c_byte = (int32_t)(lim - 1 - rbytes);
                     int32_t c_left = (int32_t)(left - (64 + TOKEN_BITS)), c_stg = (int32_t)(sleft - 256);
-                    const uint32_t gate = room >= (uint32_t)ROUND_BYTES && wsize >= 32768u ? 0u : 0x80000000u;
+                    const uint32_t gate = wsize >= 32768u ? 0u : 0x80000000u;
                     // (history available in front of the round; once it covers the window the test cannot fail, and it is
                     // made all the same: two vector instructions and an AND where a test of a flag costs three scalar ones)
                     const uint32_t avail_sat = avail < 32768u ? avail : 0x40000000u;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         const uint32_t incl = wave_scan_add(ol);
                         // output offset inside the round: bytes of the round so far (ROUND_BYTES - 1 - c_byte) + what this
                         // window puts in front of the lane's token; the uniform part is taken off on the vector side
-                        ooff = ((incl - ol) - (uint32_t)c_byte) + ((uint32_t)ROUND_BYTES - 1);
+                        ooff = ((incl - ol) - (uint32_t)c_byte) + (lim - 1);
                         mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(matchmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)matchmask, 0));
                         const uint32_t qslot = (mrank - (uint32_t)c_tok) + ((uint32_t)QCAP - 1);   // queue slot of the lane's match
                         // the usual window: no token for the scalar step, everything fits the round with a byte and a
@@ -661,10 +664,11 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         // straight on to the next window while the round, the staged input and the input's end allow
                         if (__builtin_expect((fits | c_left | c_stg) < 0, 0)) { cut_window = false; break; }
                     }
-                    rbytes = (uint32_t)ROUND_BYTES - 1 - (uint32_t)c_byte;
+                    rbytes = lim - 1 - (uint32_t)c_byte;
                     ntok = (uint32_t)QCAP - 1 - (uint32_t)c_tok;
                     P += Pw - Pw0;
                     if (cut_window) {
+                        COUNT(6, 1);
                         const uint32_t have = avail + ooff;                    // deflate.lisp:329-331
                         const uint64_t hardmask = mask & (stopmask | (matchmask & __builtin_amdgcn_ballot_w64(distance > (have < wsize ? have : wsize))) |
                                                           __builtin_amdgcn_ballot_w64((uint64_t)ooff + ol > (uint64_t)room));
@@ -678,6 +682,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                             keep = mask & ((1ull << c) - 1);
                             adv = c;
                             careful = (hardmask >> c) & 1;
+                            if (careful) COUNT(7, 1);
                             rbytes = (uint32_t)__builtin_amdgcn_readlane((int)ooff, (int)c);
                         } else {
                             rbytes = (uint32_t)__builtin_amdgcn_readlane((int)(ooff + ol), 63);
@@ -704,8 +709,6 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         uint32_t v15 = __brev(x) >> 17, idx = 0;
                         cl = canon_find(L.lit, v15, 1, 15, idx);
                         e = lit_entry(uni((uint32_t)L.lit_sorted[idx]), cl);
-                        COUNT(6, 1);
-                        if (e & LIT_FLAG) COUNT(7, 1);
                     }
                     if (short_of(lit_full ? (uint32_t)lit_max : cl)) FAIL(SEMZ_EOF, 0)
                     P += cl;

@@ -23,5 +23,5 @@ for i, n in enumerate(names):
 win, tok, careful, rounds, far, near = (st[6 + i] / units for i in range(6))
 print(f"per unit: windows {win:.0f} window tokens {tok:.0f} ({tok / max(1, win):.2f} per window) scalar steps {careful:.0f} rounds {rounds:.0f} "
       f"matches resolved together (source in front of the round) {far:.0f}, one after the other (source inside the round) {near:.0f}")
-print(f"scalar steps on a literal/length code beyond the root table: {st[12] / units:.0f} per unit, literals among them {st[13] / units:.0f}")
+print(f"windows not kept whole: {st[12] / units:.0f} per unit, of them for the scalar step {st[13] / units:.0f}")
 print(f"ticks per token: total {tot / units / max(1, tok + careful):.0f}  decode only {st[0] / units / max(1, tok + careful):.0f}")
