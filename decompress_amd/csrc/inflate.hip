@@ -209,24 +209,32 @@ __device__ __forceinline__ void build_tree(const uint8_t *lens, int n, TreeMeta 
         join_lanes();
         lds_sync();
     }
-    // 2. canonical bookkeeping by one lane
-    if (lane == 0) {
-        uint32_t code = 0, off = 0, total = 0, minl = 20, maxl = 1;
-        m.first[0] = 0; m.offs[0] = 0; m.limit[0] = 0;
-        for (int l = 1; l <= 15; l++) {
-            uint32_t cnt = m.count[l];
-            code <<= 1;
-            m.first[l] = (uint16_t)code;
-            m.offs[l] = (uint16_t)off;
-            code += cnt;
-            off += cnt;
-            m.limit[l] = code << (15 - l);
-            total += cnt << (15 - l);
-            if (cnt) { if ((uint32_t)l < minl) minl = l; maxl = l > 1 ? l : 1; }
+    // 2. canonical bookkeeping, lanes = lengths: limit[l] = sum over k <= l of count[k] << (15 - k) is a prefix sum,
+    //    first[l] = limit[l - 1] >> (15 - l), offs[l] the counts in front (one lane walking the fifteen lengths took
+    //    a quarter of the three trees' time)
+    {
+        const uint32_t cnt = lane >= 1 && lane <= 15 ? m.count[lane & 15] : 0u;
+        const uint32_t wgt = cnt << (15 - (lane & 15));
+        uint32_t iw = wgt, ic = cnt;
+#define ROW_SCAN(v, ctl) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctl, 0xf, 0xf, false)
+        ROW_SCAN(iw, 0x111); ROW_SCAN(ic, 0x111);      // row_shr:1, 2, 4, 8: the sixteen lanes of the first row
+        ROW_SCAN(iw, 0x112); ROW_SCAN(ic, 0x112);
+        ROW_SCAN(iw, 0x114); ROW_SCAN(ic, 0x114);
+        ROW_SCAN(iw, 0x118); ROW_SCAN(ic, 0x118);
+#undef ROW_SCAN
+        if (lane < 16) {
+            m.first[lane] = (uint16_t)(lane ? (iw - wgt) >> (15 - lane) : 0u);
+            m.offs[lane] = (uint16_t)(ic - cnt);
+            m.limit[lane] = iw;
         }
-        m.minlen = minl;
-        m.maxlen = maxl;
-        m.status = total < 32768u ? SEMZ_E_HUFF_UNDERFULL : total > 32768u ? SEMZ_E_HUFF_OVERFULL : SEMZ_OK;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)iw, 15);
+        const uint32_t used = (uint32_t)__builtin_amdgcn_ballot_w64(cnt != 0);
+        if (lane == 0) {
+            m.minlen = used ? (uint32_t)__builtin_ctz(used) : 20u;
+            m.maxlen = used ? 31u - (uint32_t)__builtin_clz(used) : 1u;
+            m.status = total < 32768u ? SEMZ_E_HUFF_UNDERFULL : total > 32768u ? SEMZ_E_HUFF_OVERFULL : SEMZ_OK;
+        }
+        join_lanes();
     }
     lds_sync();
     if (uni(m.status) != SEMZ_OK) return;
@@ -254,17 +262,23 @@ __device__ __forceinline__ void build_tree(const uint8_t *lens, int n, TreeMeta 
         join_lanes();
         lds_sync();
     }
-    // 4. root table, one index per lane per step (per-lane search: plain loads, no uni())
+    // 4. root table, one index per lane per step.  The length of the code an index starts with is one more than
+    //    the number of limits at or below it (the limits are in scalar registers, one compare and one add each; a
+    //    search loop that left at the first limit above ran as long as the longest code for every lane), and what
+    //    turns the code into its place in `sorted`, offs[l] - first[l], waits in `count`, free by now.
+    if (lane < 16) m.count[lane] = (uint16_t)(m.offs[lane] - m.first[lane]);
+    uint32_t lim[ROOT_BITS + 1];
+#pragma unroll
+    for (int l = 1; l <= ROOT_BITS; l++) lim[l] = uni(m.limit[l]);
+    lds_sync();
     for (int i = lane; i < (1 << ROOT_BITS); i += 64) {
         const uint32_t v15 = (__brev((uint32_t)i) >> (32 - ROOT_BITS)) << (15 - ROOT_BITS);
-        RootT ent = 0;
-        for (int l = 1; l <= ROOT_BITS; l++) {
-            if (v15 < m.limit[l]) {
-                ent = (RootT)make_entry((uint32_t)sorted[m.offs[l] + (v15 >> (15 - l)) - m.first[l]], (uint32_t)l);
-                break;
-            }
-        }
-        root[i] = ent;
+        uint32_t l = 1;
+#pragma unroll
+        for (int k = 1; k < ROOT_BITS; k++) l += v15 >= lim[k];
+        const uint32_t at = (uint16_t)(m.count[l] + (v15 >> (15 - l)));
+        const RootT ent = (RootT)make_entry((uint32_t)sorted[at < (uint32_t)n ? at : 0u], l);
+        root[i] = v15 < lim[ROOT_BITS] ? ent : (RootT)0;
     }
     lds_sync();
 }
