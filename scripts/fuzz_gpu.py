@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer check, run on the GPU box: many more damaged streams than the test suite holds, each decoded by the
+"""Developer check, run on the GPU box: many more damaged streams (deflate family, bzip2 blocks, raw LZMA2 units) than the test suite holds, each decoded by the
 engine (through the C ABI, as the tests do) and by the oracle, compared on status, detail and bytes.  Seeds are
 printed so that a failure can be replayed.  usage: python3 scripts/fuzz_gpu.py [cases] [seed]"""
 import bz2
@@ -76,6 +76,40 @@ def main():
         if (t + 1) % 50 == 0:
             print(f"bzip2: {t + 1} cases", flush=True)
     print("bzip2 statuses:", dict(sorted(seen.items())), flush=True)
+    # raw LZMA2 units, batches of 64, lc / lp / pb and dictionary sizes varied
+    import lzma
+    seen = {}
+    for t in range(cases // 64):
+        blobs, dicts, caps = [], [], []
+        for _ in range(64):
+            n = rng.choice([100, 3000, 40000, 150000])
+            d = gens[rng.randrange(4)](n, seed=rng.randrange(1 << 30))
+            lc, lp = rng.choice([(3, 0), (0, 0), (1, 2), (0, 4), (4, 0)])
+            ds = rng.choice([4096, 1 << 16, 1 << 20])
+            f = [{"id": lzma.FILTER_LZMA2, "preset": rng.choice([0, 2, 6]), "dict_size": ds, "lc": lc, "lp": lp, "pb": rng.choice([0, 2, 4])}]
+            blob = lzma.compress(d, lzma.FORMAT_RAW, filters=f)
+            blobs.append(damage(blob, rng) if rng.randrange(8) else blob)
+            dicts.append(ds if rng.randrange(4) else 4096)
+            caps.append(n + rng.choice([0, 16, 5000]))
+        data = b"".join(blobs)
+        units, off, ooff = [], 0, 0
+        for bl, ds, cap in zip(blobs, dicts, caps):
+            units.append(_lib.Unit(in_off=off, in_limit=off + len(bl), out_off=ooff, out_cap=cap, kind=_lib.UNIT_LZMA2, param0=ds))
+            off += len(bl)
+            ooff += cap + 8
+        out, res = eng.decode_batch(data, units, ooff)
+        for i, (u, r, bl) in enumerate(zip(units, res, blobs)):
+            er, eo = oracle.lzma2(bl, u.param0, cap=u.out_cap)
+            assert r.status == er.status, ("lzma2", seed, t, i, r.status, er.status, r.detail, er.detail)
+            if er.status == 0:
+                assert out.raw[u.out_off:u.out_off + r.out_len] == eo, ("lzma2", seed, t, i)
+                assert r.in_end_bit - 8 * u.in_off == er.in_end_bit, ("lzma2", seed, t, i)
+            else:
+                assert r.detail == er.detail, ("lzma2", seed, t, i, r.status, r.detail, er.detail)
+            seen[er.status] = seen.get(er.status, 0) + 1
+        if (t + 1) % 10 == 0:
+            print(f"lzma2: {64 * (t + 1)} cases", flush=True)
+    print("lzma2 statuses:", dict(sorted(seen.items())), flush=True)
     eng.close()
     print("ok")
 
