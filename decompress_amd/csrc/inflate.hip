@@ -67,7 +67,7 @@ constexpr int RING = 4096;               // output staging ring (bytes)
 constexpr int RING_MASK = RING - 1;
 constexpr int ROUND_BYTES = 2048;        // a round stops once it has produced this many bytes
 constexpr int FLUSH_BYTES = 16 * 64;     // one 16-byte store per lane
-constexpr int QCAP = 64;                 // match / stored tokens per round (one per lane when they are resolved)
+constexpr int QCAP = 128;                // match / stored tokens per round (two per lane when they are resolved)
 constexpr int IN_RING = 1024;            // compressed-input staging ring (bytes)
 constexpr int IN_PIECE = 512;            // staged in pieces of 64 lanes x 8 bytes
 constexpr int TOKEN_BITS = 48;           // longest token: 15 + 5 + 15 + 13
@@ -104,13 +104,14 @@ struct __align__(16) UnitLds {
     uint16_t dist_root[1 << DIST_ROOT_BITS];
     uint16_t lit_sorted[288];
     uint8_t dist_sorted[32];
-    uint8_t clen_sorted[32];
     uint8_t clen_root[1 << CLEN_ROOT_BITS];
-    uint8_t lens[320];
-    uint8_t clens[32];
+    uint8_t lens[320];                   // (the code-length tree's own description lives in here while it is needed:
+    uint8_t clens[32];                   //  CLEN_SORTED_AT, CLEN_META_AT -- it is dead before the first length is stored)
     uint8_t flags[64];
-    TreeMeta lit, dist, clen;
+    TreeMeta lit, dist;
 };
+constexpr int CLEN_SORTED_AT = 96, CLEN_META_AT = 128;   // offsets into UnitLds::lens
+static_assert(CLEN_SORTED_AT + 32 <= CLEN_META_AT && CLEN_META_AT % 8 == 0 && CLEN_META_AT + sizeof(TreeMeta) <= 320, "the code-length tree fits `lens`");
 static_assert(sizeof(UnitLds) <= 10240, "sixteen units per CU");
 static_assert(__builtin_offsetof(UnitLds, lens) % 8 == 0 && sizeof(((UnitLds *)nullptr)->lens) >= 8 * 40 &&
               8 * 40 * 8 >= ROUND_BYTES + 258, "the resolve step's bitmap of match starts lives in `lens`");
@@ -854,10 +855,13 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
         // positions >= near_lo live in the ring; older ones are in HBM (flushed), negative ones in the preset dictionary
         const int64_t near_lo = (int64_t)pos1 > RING ? (int64_t)pos1 - RING : 0;
         if (ntok) {
-            const uint2 tk = lane < ntok ? L.queue[lane] : make_uint2(0, 0);
-            const bool is_match = (tk.x & 3) == T_MATCH;
-            const uint32_t tlen = (tk.x >> 2) & 0x3FFF, tdoff = tk.x >> 16;
-            const int32_t tsrel = (int32_t)tdoff - (int32_t)tk.y;           // source position relative to pos0
+            // (lane l holds tokens l and 64 + l; the second half only when the round has that many)
+            uint2 tk[2];
+            bool indep[2];
+            uint32_t tdoff[2], poff[2];
+            int32_t tsrel[2];
+            uint64_t nearm[2] = {0, 0}, rawm[2] = {0, 0}, indepm[2] = {0, 0};
+            uint32_t PB = 0;
             // A match whose whole source lies before the round's first byte depends on nothing produced in this
             // round (the round's literals are already in the ring).  All such matches are resolved together with
             // lanes = bytes: an exclusive prefix sum of their lengths lays their bytes out back to back, and for
@@ -865,13 +869,26 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
             // from LDS and loads its byte -- from the ring, from HBM (older than the ring: written by this wave,
             // read back through L2) or from the preset dictionary.  Four such 64-byte chunks are in flight per
             // pass.  The other matches read bytes of this round and follow, in token order.
-            const bool indep = is_match && tsrel + (int32_t)tlen <= 0;
-            const uint32_t plen = indep ? tlen : 0u;
-            const uint32_t pincl = wave_scan_add(plen), poff = pincl - plen;
-            const uint32_t PB = (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
-            uint64_t nearm = __builtin_amdgcn_ballot_w64(is_match && !indep);
-            uint64_t rawm = __builtin_amdgcn_ballot_w64((tk.x & 3) == T_RAW);
-            COUNT(4, (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(indep))); COUNT(5, (uint32_t)__builtin_popcountll(nearm));
+            auto take_half = [&](const int h) {
+                tk[h] = lane + 64u * h < ntok ? L.queue[lane + 64u * h] : make_uint2(0, 0);
+                const bool is_match = (tk[h].x & 3) == T_MATCH;
+                const uint32_t tlen = (tk[h].x >> 2) & 0x3FFF;
+                tdoff[h] = tk[h].x >> 16;
+                tsrel[h] = (int32_t)tdoff[h] - (int32_t)tk[h].y;        // source position relative to pos0
+                indep[h] = is_match && tsrel[h] + (int32_t)tlen <= 0;
+                const uint32_t plen = indep[h] ? tlen : 0u;
+                const uint32_t pincl = wave_scan_add(plen);
+                poff[h] = PB + pincl - plen;
+                PB += (uint32_t)__builtin_amdgcn_readlane((int)pincl, 63);
+                nearm[h] = __builtin_amdgcn_ballot_w64(is_match && !indep[h]);
+                rawm[h] = __builtin_amdgcn_ballot_w64((tk[h].x & 3) == T_RAW);
+                indepm[h] = __builtin_amdgcn_ballot_w64(indep[h]);
+            };
+            take_half(0);
+            tk[1] = make_uint2(0, 0); indep[1] = false; tdoff[1] = 0; poff[1] = 0; tsrel[1] = 0;
+            if (ntok > 64) take_half(1);
+            COUNT(4, (uint32_t)__builtin_popcountll(indepm[0]) + (uint32_t)__builtin_popcountll(indepm[1]));
+            COUNT(5, (uint32_t)__builtin_popcountll(nearm[0]) + (uint32_t)__builtin_popcountll(nearm[1]));
             if (PB) {
                 // Which match a byte belongs to: the starts of the matches' byte ranges are bits of a bitmap over the
                 // PB bytes (one LDS atomic per match and round), and a byte's match is the r-th of them, r = the
@@ -883,15 +900,19 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 // by bpermute: 60 instructions and three LDS round trips per chunk where this takes half.)
                 uint32_t *const bitmap = reinterpret_cast<uint32_t *>(L.lens);          // 320 bytes: 2,305 bits at most
                 uint32_t *const packed = reinterpret_cast<uint32_t *>(L.queue);         // (the queue is in registers by now)
-                const uint64_t indepm = __builtin_amdgcn_ballot_w64(indep);
-                const uint32_t irank = __builtin_amdgcn_mbcnt_hi((uint32_t)(indepm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)indepm, 0));
                 lds_sync();
                 if (lane < 40) reinterpret_cast<uint2 *>(bitmap)[lane] = make_uint2(0, 0);
                 join_lanes();
                 lds_sync();
-                if (indep) {
-                    __hip_atomic_fetch_or(&bitmap[poff >> 5], 1u << (poff & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    packed[irank] = ((uint32_t)(tsrel - (int32_t)poff) & 0x3FFFFu) | ((uint32_t)((int32_t)tdoff - (int32_t)poff) << 18);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t irank = (h ? (uint32_t)__builtin_popcountll(indepm[0]) : 0u) +
+                                           __builtin_amdgcn_mbcnt_hi((uint32_t)(indepm[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)indepm[h], 0));
+                    if (indep[h]) {
+                        __hip_atomic_fetch_or(&bitmap[poff[h] >> 5], 1u << (poff[h] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        packed[irank] = ((uint32_t)(tsrel[h] - (int32_t)poff[h]) & 0x3FFFFu) | ((uint32_t)((int32_t)tdoff[h] - (int32_t)poff[h]) << 18);
+                    }
+                    join_lanes();
                 }
                 join_lanes();
                 lds_sync();
@@ -925,7 +946,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                     }
 #pragma unroll
                     for (int c = 0; c < NC; c++) {
-                        w[c] = packed[(before + r[c] - 1) & 63];
+                        w[c] = packed[(before + r[c] - 1) & (QCAP - 1)];
                         before += (uint32_t)__builtin_amdgcn_readlane((int)r[c], 63);
                     }
                     uint64_t negm = 0;
@@ -968,21 +989,31 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                 }
             }
             // stored spans straight from the input
-            while (rawm) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(rawm);
-                rawm &= rawm - 1;
-                const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)tk.x, (int)j);
-                const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)tk.y, (int)j);
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+              uint64_t rm = h ? rawm[1] : rawm[0];
+              const uint32_t vx = h ? tk[1].x : tk[0].x, vy = h ? tk[1].y : tk[0].y;
+              while (rm) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(rm);
+                rm &= rm - 1;
+                const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)vx, (int)j);
+                const uint32_t ty = (uint32_t)__builtin_amdgcn_readlane((int)vy, (int)j);
                 const uint32_t len = (tx >> 2) & 0x3FFF;
                 const uint32_t p = (uint32_t)(pos0 + (tx >> 16)) + shift;
                 const uint8_t *s = in + un.in_off + ty;
                 for (uint32_t k0 = 0; k0 < len; k0 = uni(k0 + 64))
                     if (k0 + lane < len) L.ring[(p + k0 + lane) & RING_MASK] = s[k0 + lane];
+              }
             }
-            // near matches in token order; LDS operations of one wave execute in order
+            // near matches in token order (the lanes' first tokens, then their second ones); LDS operations of one
+            // wave execute in order
             // (what the round has in front of it, saturated: a source can only begin in the preset history while this is small)
             const uint32_t hist32 = pos0 < 0x7FFFFFFFull ? (uint32_t)pos0 : 0x7FFFFFFFu;
-            while (nearm) {
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+              uint64_t nm = h ? nearm[1] : nearm[0];
+              const uint32_t vx = h ? tk[1].x : tk[0].x, vy = h ? tk[1].y : tk[0].y;
+              while (nm) {
                 if (ring_at_0) {
                     // The usual ones (at most 64 bytes, at least as far back as long, the source in the output) one
                     // after the other without leaving the block: 26 instructions and one taken branch a match where
@@ -1020,16 +1051,16 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                                  "s_cmp_lg_u64 %[nm], 0\n\t"
                                  "s_cbranch_scc1 1b\n"
                                  "2:"
-                                 : [nm] "+s"(nearm), [ex] "=&s"(ex), [j] "=&s"(sj), [tx] "=&s"(stx), [d] "=&s"(sd), [len] "=&s"(slen),
+                                 : [nm] "+s"(nm), [ex] "=&s"(ex), [j] "=&s"(sj), [tx] "=&s"(stx), [d] "=&s"(sd), [len] "=&s"(slen),
                                    [doff] "=&s"(sdoff), [t] "=&s"(st0), [p] "=&s"(sp), [a] "=&v"(va), [b] "=&v"(vb), [v] "=&v"(vv)
-                                 : [vx] "v"(tk.x), [vy] "v"(tk.y), [lane] "v"(lane), [hist] "s"(hist32), [base] "s"((uint32_t)pos0 + shift)
+                                 : [vx] "v"(vx), [vy] "v"(vy), [lane] "v"(lane), [hist] "s"(hist32), [base] "s"((uint32_t)pos0 + shift)
                                  : "scc", "vcc", "memory");
-                    if (!nearm) break;
+                    if (!nm) break;
                 }
-                const uint32_t j = (uint32_t)__builtin_ctzll(nearm);
-                nearm &= nearm - 1;
-                const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)tk.x, (int)j);
-                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)tk.y, (int)j);
+                const uint32_t j = (uint32_t)__builtin_ctzll(nm);
+                nm &= nm - 1;
+                const uint32_t tx = (uint32_t)__builtin_amdgcn_readlane((int)vx, (int)j);
+                const uint32_t dist = (uint32_t)__builtin_amdgcn_readlane((int)vy, (int)j);
                 const uint32_t len = (tx >> 2) & 0x3FFF;
                 const uint32_t p = (uint32_t)(pos0 + (tx >> 16)) + shift;     // ring index of the destination
                 const uint32_t src = p - dist;
@@ -1070,6 +1101,7 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
                         if (k < len) L.ring[(p + k) & RING_MASK] = (uint8_t)v;
                     }
                 }
+              }
             }
         }
         pos = pos1;
@@ -1118,11 +1150,12 @@ __global__ __launch_bounds__(64, 4) void inflate_kernel(const uint8_t *in, uint6
             long overread = 0;
             if (ev == EV_DYN) {
                 // code-length tree, then the code lengths themselves (deflate.lisp:176-197)
-                build_tree<CLEN_ROOT_BITS>(L.clens, 19, L.clen, L.clen_sorted, L.clen_root, clen_entry);
-                const int tstatus = (int)uni(L.clen.status);
+                TreeMeta &clen_meta = *reinterpret_cast<TreeMeta *>(L.lens + CLEN_META_AT);
+                build_tree<CLEN_ROOT_BITS>(L.clens, 19, clen_meta, L.lens + CLEN_SORTED_AT, L.clen_root, clen_entry);
+                const int tstatus = (int)uni(clen_meta.status);
                 overread = (final_block ? 0 : MIN_BLOCK_BITS) + trailing_bits;    // deflate.lisp:392-396
                 if (tstatus == SEMZ_OK) {
-                    const uint32_t cminl = uni(L.clen.minlen), cmaxl = uni(L.clen.maxlen);
+                    const uint32_t cminl = uni(clen_meta.minlen), cmaxl = uni(clen_meta.maxlen);
                     const bool cfull = overread >= (long)(cmaxl - cminl);
                     const int total = nlit + ndist;
                     int i = 0;
