@@ -162,6 +162,33 @@ def test_faults_in_the_dynamic_header(engine):
     assert len(seen) >= 4, seen                                         # (several different failures among them)
 
 
+def test_more_than_64_tokens_in_a_round(engine):
+    """A round of a unit with more than 8 KiB of room holds up to 128 queued tokens, two per lane when they are resolved
+    (64 for smaller units).  Short-match text, then bytes that only a stored block takes, then text again, all inside
+    2 KiB of output and flushed into blocks of their own: matches and stored spans in either half of the queue, matches
+    of the second half that copy from spans and matches of the first.  The same streams with little room take the
+    64-token road."""
+    items = []
+    for seed in range(24):
+        rng = random.Random(seed)
+        co = zlib.compressobj(9, zlib.DEFLATED, -15)
+        blob, plain = b"", b""
+        for k in range(rng.choice([3, 5, 8])):
+            if k % 2 == 0:
+                d = corpus.text(rng.choice([500, 900, 1400]), seed=100 * seed + k)
+                if plain and rng.randrange(2):
+                    d = d[:200] + plain[-150:] + d[200:]              # copies out of what came before
+            else:
+                d = corpus.random_bytes(rng.choice([40, 300, 700]), seed=100 * seed + k)
+            plain += d
+            blob += co.compress(d) + co.flush(rng.choice([zlib.Z_FULL_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_BLOCK]))
+        blob += co.flush()
+        assert zlib.decompress(blob, -15) == plain
+        items.append((0, blob, len(plain) + 9000))
+        items.append((0, blob, len(plain) + rng.choice([0, 5])))
+    check_items(engine, items, 64)
+
+
 def test_trailer_mismatches(engine):
     d = corpus.text(5000, seed=5)
     g = bytearray(compress(2, d))
