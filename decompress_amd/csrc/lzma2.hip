@@ -671,6 +671,121 @@ __global__ __launch_bounds__(64) void bcj_x86_kernel(const semz_unit *units, uin
     uint32_t prev_mask = 0, prev_pos = 0u - 5u;
     if ((uint32_t)(now_pos0 - prev_pos) > 5) prev_pos = now_pos0 - 5;
     uint64_t next_i = 0;                               // first byte not yet consumed by the state machine
+    if (((uintptr_t)ob & 15) == 0) {
+        // The usual block starts on a 16-byte boundary: a piece is one 16-byte load and one 16-byte store a lane, the
+        // candidate bits come out of the registers (a byte is E8 or E9 when (b ^ E8) & FE is zero: the zero-byte test
+        // on four bytes at a time, squeezed to four bits by a multiplication), the next piece is on its way while
+        // this one's candidates are visited, and the four bytes behind a piece, which an operand that straddles
+        // the boundary patches, are handed on in LDS instead of through memory.  (Byte loads, a byte-wise scan and
+        // no load in flight made this kernel 8 ms of the xz step.)
+        auto load_piece = [&](uint64_t base) -> uint4 {
+            const uint64_t at = base + 16 * lane;
+            uint4 x = make_uint4(0, 0, 0, 0);
+            if (at + 16 <= n) x = *reinterpret_cast<const uint4 *>(ob + at);
+            else if (at < n) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; k < 16 && at + k < n; k++) w[k >> 2] |= (uint32_t)ob[at + k] << (8 * (k & 3));
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            return x;
+        };
+        uint4 cur = load_piece(0);
+        uint32_t carry = 0;                                 // the piece's first four bytes as the piece before left them
+        for (uint64_t base = 0; base <= limit; base += BCJ_PIECE) {
+            if (base) cur.x = lane == 0 ? carry : cur.x;
+            *reinterpret_cast<uint4 *>(buf + 16 * lane) = cur;
+            // the four bytes behind the piece and the next piece, while this one is worked on
+            const uint4 nxt = load_piece(base + BCJ_PIECE);
+            if (lane == 0) *reinterpret_cast<uint32_t *>(buf + BCJ_PIECE) = nxt.x;
+            {
+                const uint32_t ws[4] = {cur.x, cur.y, cur.z, cur.w};
+                uint32_t m = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t t = (ws[q] ^ 0xE8E8E8E8u) & 0xFEFEFEFEu;
+                    const uint32_t z = (t - 0x01010101u) & ~t & 0x80808080u;      // 0x80 in every byte that is zero (no byte of t is 1)
+                    m |= ((((z >> 7) * 0x00204081u) >> 21) & 15u) << (4 * q);
+                }
+                const uint64_t first = base + 16 * lane;
+                const uint32_t valid = first > limit ? 0u : (limit - first >= 15 ? 16u : (uint32_t)(limit - first) + 1u);
+                m &= (1u << valid) - 1;
+                reinterpret_cast<uint16_t *>(cand)[lane] = (uint16_t)m;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // (the bitmap comes back as one register, lane w = word w, and only the words that hold a candidate are
+            // visited; a candidate's five bytes come in one LDS round trip, two aligned words and a shift)
+            const uint32_t candv = cand[lane & (BCJ_PIECE / 32 - 1)];
+            uint32_t wordm = (uint32_t)__builtin_amdgcn_ballot_w64(lane < BCJ_PIECE / 32 && candv != 0);
+            while (wordm) {
+                const uint32_t w = (uint32_t)__builtin_ctz(wordm);
+                wordm &= wordm - 1;
+                uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)candv, (int)w);
+                while (m) {
+                    const uint32_t bitn = __builtin_ctz(m);
+                    m &= m - 1;
+                    const uint32_t li = 32 * w + bitn;                  // index inside the piece
+                    const uint64_t i = base + li;
+                    if (i < next_i) continue;                            // inside an operand that was converted
+                    const uint32_t offset = now_pos0 + (uint32_t)i - prev_pos;
+                    prev_pos = now_pos0 + (uint32_t)i;
+                    if (offset > 5) prev_mask = 0;
+                    else for (uint32_t k = 0; k < offset; k++) prev_mask = (prev_mask & 0x77) << 1;
+                    const uint32_t *bw = reinterpret_cast<const uint32_t *>(buf + ((li + 1) & ~3u));
+                    const uint32_t opnd = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)(uint32_t)(((((uint64_t)bw[1] << 32) | bw[0]) >> (8 * ((li + 1) & 3)))));   // bytes li + 1 .. li + 4
+                    uint32_t b = opnd >> 24;
+                    const bool allowed = (0x17u >> ((prev_mask >> 1) & 7)) & 1;   // t t t nil t nil nil nil
+                    if ((b == 0x00 || b == 0xFF) && allowed && (prev_mask >> 1) < 0x10) {
+                        uint32_t src = opnd;
+                        uint32_t dest;
+                        for (;;) {
+                            dest = src - (now_pos0 + (uint32_t)i + 5);
+                            if (prev_mask == 0) break;
+                            const uint32_t j = (0x33332210u >> (4 * (prev_mask >> 1))) & 15;   // 0 1 2 2 3 3 3 3
+                            b = (dest >> (24 - 8 * j)) & 0xFF;
+                            if (!(b == 0x00 || b == 0xFF)) break;
+                            src = dest ^ ((1u << (32 - 8 * j)) - 1);
+                        }
+                        if (lane == 0) {
+                            buf[li + 4] = (uint8_t)~(((dest >> 24) & 1) - 1);
+                            buf[li + 1] = (uint8_t)dest;
+                            buf[li + 2] = (uint8_t)(dest >> 8);
+                            buf[li + 3] = (uint8_t)(dest >> 16);
+                        }
+                        next_i = i + 5;
+                        prev_mask = 0;
+                    } else {
+                        next_i = i + 1;
+                        prev_mask |= 1;
+                        if (b == 0x00 || b == 0xFF) prev_mask |= 0x10;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // back to memory: the piece, and behind the block's last piece the bytes that piece patched
+            {
+                const uint4 y = *reinterpret_cast<const uint4 *>(buf + 16 * lane);
+                const uint64_t at = base + 16 * lane;
+                if (at + 16 <= n) *reinterpret_cast<uint4 *>(ob + at) = y;
+                else if (at < n) {
+                    const uint32_t ys[4] = {y.x, y.y, y.z, y.w};
+                    for (uint32_t k = 0; k < 16 && at + k < n; k++) ob[at + k] = (uint8_t)(ys[k >> 2] >> (8 * (k & 3)));
+                }
+            }
+            carry = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t *>(buf + BCJ_PIECE));
+            const bool more = base + BCJ_PIECE <= limit;
+            if (!more && lane < 4 && base + BCJ_PIECE + lane < n) ob[base + BCJ_PIECE + lane] = (uint8_t)(carry >> (8 * lane));
+            cur = nxt;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        return;
+    }
     for (uint64_t base = 0; base <= limit; base += BCJ_PIECE) {
         // stage [base, base + BCJ_PIECE + 4)
         const uint64_t span = n - base < (uint64_t)(BCJ_PIECE + 4) ? n - base : (uint64_t)(BCJ_PIECE + 4);

@@ -193,6 +193,28 @@ def test_corrupt_xz_blocks(engine):
             assert res[0].detail == er.detail, (t, res[0].status, res[0].detail, er.detail)
 
 
+def test_x86_bcj_at_any_output_alignment(engine):
+    """bcj_x86_kernel takes 16-byte loads and stores when a block's output starts on a 16-byte boundary and the byte-wise
+    road otherwise; operands that straddle its 1 KiB pieces are handed on in LDS.  The same blocks at sixteen output
+    offsets, sizes around the piece size and its multiples, against the oracle."""
+    rng = random.Random(17)
+    for n in (5, 900, 1019, 1024, 1029, 2048, 5000, 70001):
+        d = corpus.x86ish(n, seed=n)
+        data = xzutil.xz_py(d, lzma.CHECK_CRC32, [{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_LZMA2, "preset": 3}])
+        units0, _ = split(_lib.FMT_XZ, data)
+        er, eo = oracle.decompress(8, data, True, cap=n + 16)
+        assert er.status == 0 and eo == d
+        assert len(units0) == 1
+        for shift in rng.sample(range(64), 16) + [0]:
+            u = units0[0]
+            u2 = _lib.Unit(in_off=u.in_off, in_bit_off=u.in_bit_off, in_limit=u.in_limit, out_off=shift, out_cap=u.out_cap, kind=u.kind,
+                           flags=u.flags, param0=u.param0, param1=u.param1, param2=u.param2, param3=u.param3, filters=u.filters,
+                           size_in=u.size_in, size_out=u.size_out)
+            out, res = engine.decode_batch(data, [u2], shift + u.out_cap + 16)
+            assert res[0].status == 0, (n, shift, res[0].status, res[0].detail)
+            assert out.raw[shift:shift + res[0].out_len] == d, (n, shift)
+
+
 @pytest.mark.parametrize("name", ["powerpc", "ia64", "arm", "armthumb", "sparc"])
 def test_other_bcj_filters(engine, name):
     # xz-bcj-filters.lisp:45-167, chains as the reference builds them (xz.lisp:311-344)
