@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer check, run on the GPU box: many more damaged streams (deflate family, bzip2 blocks, raw LZMA2 units) than the test suite holds, each decoded by the
+"""Developer check, run on the GPU box: many more damaged streams (deflate family, bzip2 blocks, raw LZMA2 units, xz blocks behind filters) than the test suite holds, each decoded by the
 engine (through the C ABI, as the tests do) and by the oracle, compared on status, detail and bytes.  Seeds are
 printed so that a failure can be replayed.  usage: python3 scripts/fuzz_gpu.py [cases] [seed]"""
 import bz2
@@ -110,6 +110,38 @@ def main():
         if (t + 1) % 10 == 0:
             print(f"lzma2: {64 * (t + 1)} cases", flush=True)
     print("lzma2 statuses:", dict(sorted(seen.items())), flush=True)
+    # xz blocks behind filter chains (x86 BCJ, delta), damaged in the payload, padding or check
+    import xzutil
+    from test_split import split
+    seen = {}
+    for t in range(cases // 16):
+        n = rng.choice([700, 5000, 70000, 300000])
+        d = rng.choice([corpus.x86ish, corpus.mixed, corpus.text])(n, seed=rng.randrange(1 << 30))
+        filters = rng.choice([[{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_LZMA2, "preset": 3}],
+                              [{"id": lzma.FILTER_DELTA, "dist": rng.choice([1, 4, 256])}, {"id": lzma.FILTER_LZMA2, "preset": 1}],
+                              [{"id": lzma.FILTER_X86}, {"id": lzma.FILTER_DELTA, "dist": 3}, {"id": lzma.FILTER_LZMA2, "preset": 2}],
+                              [{"id": lzma.FILTER_LZMA2, "preset": 6}]])
+        base = xzutil.xz_py(d, rng.choice([lzma.CHECK_NONE, lzma.CHECK_CRC32, lzma.CHECK_CRC64, lzma.CHECK_SHA256]), filters)
+        units0, _ = split(_lib.FMT_XZ, base)
+        if len(units0) != 1:
+            continue
+        b = bytearray(base)
+        if rng.randrange(6):
+            for _ in range(rng.choice([1, 2])):
+                b[rng.randrange(units0[0].in_off, len(b) - 24)] ^= 1 << rng.randrange(8)
+        data = bytes(b)
+        u = units0[0]
+        out, res = eng.decode_batch(data, [u], u.out_cap + 16)
+        er, eo = oracle.decompress(8, data, True, cap=len(d) + 16)
+        assert res[0].status == er.status, ("xz", seed, t, res[0].status, er.status, res[0].detail, er.detail)
+        if er.status == 0:
+            assert out.raw[:res[0].out_len] == eo, ("xz", seed, t)
+        else:
+            assert res[0].detail == er.detail, ("xz", seed, t, res[0].status, res[0].detail, er.detail)
+        seen[er.status] = seen.get(er.status, 0) + 1
+        if (t + 1) % 100 == 0:
+            print(f"xz: {t + 1} cases", flush=True)
+    print("xz statuses:", dict(sorted(seen.items())), flush=True)
     eng.close()
     print("ok")
 
